@@ -1,0 +1,218 @@
+/*
+ * mp_api.h — C ABI of the MI355X spline-trajectory evaluation library (libmp_hip.so).
+ *
+ * This is the drop-in boundary for ONE hot path of Geryyy/motion_planning: batched
+ * evaluation of interpolating B-spline trajectories with the 15-term collision-aware
+ * cost, its analytic (sub)gradient, the minimum clearance and the collision /
+ * feasibility flags, plus the box-obstacle distance queries underneath it.
+ *
+ * The reference has no FFI; its seam is Python duck typing.  Every
+ * entry point below names the reference interface (file:line under the reference
+ * checkout) whose work it replaces.  Plain C: pointers and sizes only, no C++/torch
+ * types.  Every function returns 0 on success or a negative MP_E_* code; the text of
+ * the last error of a context is available from mp_last_error().
+ *
+ * Threading: a context is NOT re-entrant (callers serialise calls on one context);
+ * different contexts are independent.  One context per GPU per process.
+ */
+#ifndef MP_API_H
+#define MP_API_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MP_API_VERSION 1
+
+/* ---- limits ------------------------------------------------------------------ */
+#define MP_MAX_CTRL 16    /* waypoints per spline (start + vias + goal)            */
+#define MP_MAX_SAMPLES 1024 /* n_samples_curve                                      */
+#define MP_NTERMS 15      /* cost terms, order of the weighted sum spline_opt.py:605-621 */
+
+/* ---- error codes ------------------------------------------------------------- */
+#define MP_OK 0
+#define MP_E_ARG (-1)        /* bad argument (shape, range, NULL)                   */
+#define MP_E_STATE (-2)      /* call order: scene/problem not set                   */
+#define MP_E_HIP (-3)        /* a HIP runtime call failed (text in mp_last_error)   */
+#define MP_E_UNSUPPORTED (-4)/* valid in the reference, not implemented here yet    */
+#define MP_E_NOMEM (-5)
+
+/* ---- enums ------------------------------------------------------------------- */
+#define MP_F64 0
+#define MP_F32 1
+
+#define MP_MODEL_POINT 0 /* scene.signed_distance(p)            geom/scene.py:50-68  */
+#define MP_MODEL_BOX 1   /* scene.signed_distance_block(...)    geom/scene.py:70-122 */
+
+#define MP_MEM_HOST 0    /* X / outputs are host pointers (library stages them)    */
+#define MP_MEM_DEVICE 1  /* X / outputs are device pointers on the context's GPU   */
+
+/* index of each term in `terms[]` / `weights[]` (order of spline_opt.py:605-621)    */
+enum mp_term {
+    MP_T_LEN = 0,          /* path_length                      spline_opt.py:54-60   */
+    MP_T_CURV = 1,         /* curvature_cost                   spline_opt.py:63-79   */
+    MP_T_YAW_SMOOTH = 2,   /* yaw_smoothness_cost              spline_opt.py:100-106 */
+    MP_T_SAFE = 3,         /* sum max(0,req-d)^2               spline_opt.py:546-547 */
+    MP_T_SAFE_PREF = 4,    /* preferred clearance              spline_opt.py:548-556 */
+    MP_T_REBOUND = 5,      /* approach rebound                 spline_opt.py:559-562 */
+    MP_T_GOAL_CLEAR = 6,   /* goal clearance                   spline_opt.py:565-566 */
+    MP_T_GOAL_TARGET = 7,  /* goal clearance target            spline_opt.py:567-569 */
+    MP_T_APPROACH_CLEAR = 8, /* approach clearance             spline_opt.py:572-579 */
+    MP_T_APPROACH_COL = 9, /* approach collision               spline_opt.py:580-581 */
+    MP_T_VIA_DEV = 10,     /* via deviation                    spline_opt.py:584     */
+    MP_T_YAW_DEV = 11,     /* yaw control deviation            spline_opt.py:585     */
+    MP_T_YAW_MONO = 12,    /* yaw monotonicity                 spline_opt.py:588-593 */
+    MP_T_YAW_SCHED = 13,   /* yaw schedule                     spline_opt.py:596-598 */
+    MP_T_GOAL_NORMAL = 14  /* goal approach alignment          spline_opt.py:117-145 */
+};
+
+/* flags[] bits */
+#define MP_FLAG_COLLISION 1u /* min_k d_k <  0                                      */
+#define MP_FLAG_FEASIBLE 2u  /* min_k d_k >= required_clearance                     */
+
+/*
+ * mp_config — everything of one objective closure that does not depend on the
+ * scenario: sizes, windows, weights, clearances.  It is the POD form of the
+ * closure constants of objective_single (spline_opt.py:463-492, :500-641) and of the
+ * 3-term variant (spline_opt.py:797-819).  All windows are integers derived ON THE
+ * HOST with the reference's own floor/ceil expressions.
+ *
+ * Waypoint rows: W = [fixed head rows | free rows | fixed tail row].  For
+ * optimize_bspline_path first_free = 1 (row 0 = start); for
+ * optimize_bspline_with_vias first_free = 2 (rows 0,1 = start, via).  The optimised
+ * vector is x = [free rows (n_free x 3, row-major) | free yaw controls (n_yaw_free)],
+ * D = 3*n_free + n_yaw_free.
+ */
+typedef struct mp_config {
+    int32_t n_samples;      /* S   n_samples_curve                                   */
+    int32_t n_ctrl;         /* C   position waypoints, 4..MP_MAX_CTRL                */
+    int32_t first_free;     /* index of the first optimised waypoint row             */
+    int32_t n_free;         /* optimised waypoint rows (n_vias / n_additional_vias)  */
+    int32_t n_yaw_ctrl;     /* Cy  yaw controls incl. the two fixed ends, >= 2       */
+    int32_t n_yaw_free;     /* optimised yaw controls = Cy - 2                       */
+    int32_t model;          /* MP_MODEL_POINT / MP_MODEL_BOX                         */
+    int32_t n_safe;         /* S'  collision samples = len(idx_safe)                 */
+    int32_t last_if_not_close; /* 1: idx_safe[S'-1] was appended conditionally and is
+                                 dropped when allclose(P[idx_safe[S'-2]], P[S-1])
+                                 (spline_opt.py:802-805); 0 otherwise                */
+    int32_t keep_n;         /* preferred-clearance window d[:keep_n] (:550-554)      */
+    int32_t use_pref;       /* pref > req and w_safe_preferred > 0 (:549)            */
+    int32_t tail_start;     /* rebound window starts at d[tail_start] (:559-560)     */
+    int32_t use_goal_target;/* goal_clearance_target given and weight > 0 (:568)     */
+    int32_t goal_tail_n;    /* tail_n of _goal_approach_alignment_cost (:125)        */
+    uint32_t term_mask;     /* bit t set: term t is part of the cost.  0x7fff for
+                               optimize_bspline_path; len|curv|safe for the 3-term
+                               objective (spline_opt.py:818)                         */
+    int32_t reserved0;
+    double weights[MP_NTERMS];
+    double required_clearance;   /* :463 */
+    double preferred_clearance;  /* :464-465 */
+    double approach_target;      /* :577 */
+    double goal_clearance_target;/* :569 */
+    double point_radius;         /* geom/scene.py:50 (1e-6), point model only       */
+    double half_extents[3];      /* moving box half sizes, box model only           */
+    const int32_t *idx_safe;     /* [S'] sample index of each collision sample       */
+    const uint8_t *approach_mask;/* [S'] 1 = sample is in the approach window (:572-576,
+                                    fallback already applied by the host)            */
+    const double *basis;         /* [S x C]  row-major sampling matrix M, or NULL to
+                                    have the library build it (mp_build_basis)       */
+    const double *basis_yaw;     /* [S x Cy] same for the yaw controls, or NULL      */
+    const double *t_sched;       /* [S] clip(us / yaw_goal_reach_u, 0, 1) (:596)     */
+} mp_config;
+
+/*
+ * mp_task — the scenario-dependent closure constants: one per scenario / restart
+ * group.  Candidates of task t see boxes [box_begin, box_begin+box_count) of the
+ * scene set with mp_set_scene.
+ */
+typedef struct mp_task {
+    double ctrl[MP_MAX_CTRL][3]; /* waypoint rows: fixed rows hold start/via/goal,
+                                    free rows hold via_init (:466, used by via_dev)  */
+    double yaw_ctrl[MP_MAX_CTRL];/* yaw_ctrl_ref (:472): ends are start/goal yaw     */
+    double goal_normal[3];       /* normalised resultant of the goal normals (:134-140) */
+    int32_t has_goal_normal;     /* 0: term is 0 (:123, :141)                        */
+    int32_t yaw_increasing;      /* goal_yaw >= start_yaw (:589)                     */
+    int32_t box_begin;
+    int32_t box_count;
+} mp_task;
+
+typedef struct mp_ctx mp_ctx; /* opaque */
+
+/* ---- context ------------------------------------------------------------------ */
+
+/* Create a context on GPU `device_id` computing in `dtype` (MP_F64 / MP_F32).
+ * Fails with MP_E_HIP when no HIP device is available: there is no CPU fallback. */
+int mp_create(int device_id, int dtype, mp_ctx **out);
+int mp_destroy(mp_ctx *ctx);
+const char *mp_last_error(const mp_ctx *ctx); /* ctx may be NULL: last create error */
+int mp_api_version(void);
+
+/* Use an externally owned hipStream_t (e.g. torch's current stream) for all work of
+ * this context; NULL restores the context's own stream. */
+int mp_set_stream(mp_ctx *ctx, void *hip_stream);
+int mp_synchronize(mp_ctx *ctx);
+
+/* HIP-event timer on the context's stream (bench.py times kernels with it). */
+int mp_timer_start(mp_ctx *ctx);
+int mp_timer_stop(mp_ctx *ctx, float *elapsed_ms); /* synchronises on the stop event */
+
+/* ---- scene: replaces Scene.blocks / Block (geom/scene.py:10-45, geom/blocks.py:8-21)
+ * SoA host arrays of box centres and HALF extents.  quat_xyzw may be NULL (all
+ * identity).  Static boxes must be axis-aligned in this version: any non-identity
+ * quaternion returns MP_E_UNSUPPORTED (every shipped scenario is axis-aligned,
+ * SURVEY.md §0 F5).  n_boxes == 0 is legal: distances are +inf (scene.py:112-113). */
+int mp_set_scene(mp_ctx *ctx, int32_t n_boxes, const double *cx, const double *cy,
+                 const double *cz, const double *hx, const double *hy, const double *hz,
+                 const double *quat_xyzw /* [n_boxes x 4] or NULL */);
+
+/* ---- problem: replaces the closure built by optimize_bspline_path
+ * (geom/spline_opt.py:438-499) / optimize_bspline_with_vias (:776-796).
+ * cfg and tasks are copied (including every array cfg points to). */
+int mp_set_problem(mp_ctx *ctx, const mp_config *cfg, int32_t n_tasks, const mp_task *tasks);
+
+/* Sampling matrix of an interpolating B-spline of degree k through n points at
+ * u = linspace(0,1,n), evaluated at us = linspace(0,1,S):  P = M @ W.  Replaces the
+ * per-call make_interp_spline of build_cubic_bspline / build_scalar_bspline
+ * (geom/spline_opt.py:11-34).  Host-side, runs once per problem.  k in {1,2,3}. */
+int mp_build_basis(int32_t n_ctrl, int32_t degree, int32_t n_samples, double *M /* [S x n] */);
+/* Read back the matrices a context uses (tests feed them to the oracle). */
+int mp_get_basis(mp_ctx *ctx, double *M /* [S x C] */, double *M_yaw /* [S x Cy] or NULL */);
+
+/* ---- the hot path: replaces objective_single / objective_batch
+ * (geom/spline_opt.py:500-641, :797-819, :301-302).
+ *
+ *   X         [n x D]      candidates, row-major, element type = context dtype
+ *   task_of   [n] or NULL  task index per candidate; NULL: candidate i belongs to
+ *                          task (i / cands_per_task) — see mp_set_cands_per_task —
+ *                          (default: everything is task 0)
+ *   cost      [n]          weighted total j                         (required)
+ *   terms     [n x 15]     unweighted terms, mp_term order          (or NULL)
+ *   grad      [n x D]      d cost / d x (analytic sub-gradient)     (or NULL)
+ *   min_clear [n]          min over collision samples of d          (or NULL)
+ *   flags     [n]          MP_FLAG_* bits                           (or NULL)
+ *   dist      [n x S']     clearance profile d_safe                 (or NULL)
+ *
+ * mem = MP_MEM_HOST: synchronous, results are in the host arrays on return.
+ * mem = MP_MEM_DEVICE: asynchronous on the context's stream. */
+int mp_eval(mp_ctx *ctx, int64_t n, const void *X, const int32_t *task_of, void *cost,
+            void *terms, void *grad, void *min_clear, uint8_t *flags, void *dist, int mem);
+int mp_set_cands_per_task(mp_ctx *ctx, int64_t cands_per_task);
+
+/* ---- batched distance queries --------------------------------------------------
+ * mp_point_sdf: Scene.signed_distance (geom/scene.py:50-68) for n points [n x 3].
+ * mp_box_sdf:   Scene.signed_distance_block (geom/scene.py:70-122) for n poses of a
+ *               yaw-rotated box: pos [n x 3], yaw_deg [n], one size (full extents).
+ * Both use boxes [box_begin, box_begin+box_count) of the scene; element type =
+ * context dtype; mem as in mp_eval. */
+int mp_point_sdf(mp_ctx *ctx, int64_t n, const void *pts, double point_radius,
+                 int32_t box_begin, int32_t box_count, void *out, int mem);
+int mp_box_sdf(mp_ctx *ctx, int64_t n, const void *pos, const void *yaw_deg,
+               const double size[3], int32_t box_begin, int32_t box_count, void *out,
+               int mem);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MP_API_H */
