@@ -1,0 +1,628 @@
+// mp_api.hip — C ABI of libmp_hip.so (see include/mp_api.h).  Host side: context, device
+// buffers, problem upload, kernel launches.  There is no CPU compute path in this file:
+// without a HIP device mp_create fails and nothing else can be called.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <vector>
+
+#include "../../include/mp_api.h"
+#include "mp_kernels.hpp"
+
+namespace {
+
+thread_local char g_create_err[512] = "";
+
+struct DevBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+};
+
+}  // namespace
+
+struct mp_ctx {
+    int device = 0;
+    int dtype = MP_F64;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    char err[512] = "";
+    int num_cu = 256;
+    size_t max_lds = 65536;
+
+    // scene
+    DevBuf boxes;
+    int n_boxes = 0;
+    bool have_scene = false;
+
+    // problem
+    bool have_problem = false;
+    mp_config cfg{};
+    int n_tasks = 0;
+    long long cands_per_task = 0;
+    std::vector<double> basis, basis_yaw;
+    DevBuf d_idx, d_mask, d_M, d_My, d_tsched, d_tasks;
+
+    // staging for MP_MEM_HOST calls
+    DevBuf s_X, s_taskof, s_cost, s_terms, s_grad, s_minc, s_flags, s_dist, s_aux0, s_aux1;
+};
+
+namespace {
+
+int fail(mp_ctx *ctx, int code, const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(ctx ? ctx->err : g_create_err, 512, fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define HIP_TRY(ctx, call)                                                                          \
+    do {                                                                                            \
+        hipError_t e_ = (call);                                                                     \
+        if (e_ != hipSuccess)                                                                       \
+            return fail((ctx), MP_E_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+
+int reserve(mp_ctx *ctx, DevBuf &b, size_t bytes)
+{
+    if (bytes <= b.cap && b.p) return MP_OK;
+    if (b.p) HIP_TRY(ctx, hipFree(b.p));
+    b.p = nullptr;
+    b.cap = 0;
+    size_t want = std::max<size_t>(bytes, 256);
+    HIP_TRY(ctx, hipMalloc(&b.p, want));
+    b.cap = want;
+    return MP_OK;
+}
+
+int upload(mp_ctx *ctx, DevBuf &b, const void *src, size_t bytes)
+{
+    int rc = reserve(ctx, b, bytes);
+    if (rc) return rc;
+    if (bytes) HIP_TRY(ctx, hipMemcpyAsync(b.p, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+    return MP_OK;
+}
+
+size_t esize(const mp_ctx *ctx) { return ctx->dtype == MP_F64 ? 8 : 4; }
+
+// ---- interpolating B-spline sampling matrix (host, once per problem) --------------------
+// Restates what scipy.interpolate.make_interp_spline(u, y, k) with bc_type=None does for
+// u = linspace(0,1,n) (not-a-knot knots), as a constant matrix: P = M @ W.
+void linspace01(int n, std::vector<double> &out)
+{
+    out.resize(n);
+    const double step = 1.0 / (double)(n - 1);
+    for (int i = 0; i < n; ++i) out[i] = (double)i * step;
+    out[n - 1] = 1.0;
+}
+
+void basis_funs(const std::vector<double> &t, int k, int n, double x, int &first, long double N[4])
+{
+    // span: t[i] <= x < t[i+1], clamped to the last non-empty interval
+    int i = k;
+    while (i < n - 1 && x >= t[i + 1]) ++i;
+    long double left[4], right[4];
+    N[0] = 1.0L;
+    for (int j = 1; j <= k; ++j) {
+        left[j] = (long double)x - (long double)t[i + 1 - j];
+        right[j] = (long double)t[i + j] - (long double)x;
+        long double saved = 0.0L;
+        for (int r = 0; r < j; ++r) {
+            long double tmp = N[r] / (right[r + 1] + left[j - r]);
+            N[r] = saved + right[r + 1] * tmp;
+            saved = left[j - r] * tmp;
+        }
+        N[j] = saved;
+    }
+    first = i - k;
+}
+
+int build_basis(int n, int k, int S, double *M)
+{
+    if (k < 1 || k > 3 || n < k + 1 || n > MP_MAX_CTRL || S < 2) return MP_E_ARG;
+    std::vector<double> u, us, t;
+    linspace01(n, u);
+    linspace01(S, us);
+    for (int i = 0; i <= k; ++i) t.push_back(u[0]);
+    if (k % 2 == 1) {
+        const int k2 = (k + 1) / 2;
+        for (int i = k2; i < n - k2; ++i) t.push_back(u[i]);
+    } else {
+        for (int i = 1; i + 2 < n; ++i) t.push_back(0.5 * (u[i] + u[i + 1]));
+    }
+    for (int i = 0; i <= k; ++i) t.push_back(u[n - 1]);
+    if ((int)t.size() != n + k + 1) return MP_E_ARG;
+
+    // collocation matrix and its inverse (Gauss-Jordan, partial pivoting, long double)
+    std::vector<long double> A((size_t)n * n, 0.0L), Inv((size_t)n * n, 0.0L);
+    for (int r = 0; r < n; ++r) {
+        int first;
+        long double N[4];
+        basis_funs(t, k, n, u[r], first, N);
+        for (int j = 0; j <= k; ++j) A[(size_t)r * n + first + j] = N[j];
+        Inv[(size_t)r * n + r] = 1.0L;
+    }
+    for (int c = 0; c < n; ++c) {
+        int piv = c;
+        for (int r = c + 1; r < n; ++r)
+            if (fabsl(A[(size_t)r * n + c]) > fabsl(A[(size_t)piv * n + c])) piv = r;
+        if (A[(size_t)piv * n + c] == 0.0L) return MP_E_ARG;
+        if (piv != c)
+            for (int j = 0; j < n; ++j) {
+                std::swap(A[(size_t)piv * n + j], A[(size_t)c * n + j]);
+                std::swap(Inv[(size_t)piv * n + j], Inv[(size_t)c * n + j]);
+            }
+        long double d = A[(size_t)c * n + c];
+        for (int j = 0; j < n; ++j) { A[(size_t)c * n + j] /= d; Inv[(size_t)c * n + j] /= d; }
+        for (int r = 0; r < n; ++r) {
+            if (r == c) continue;
+            long double f = A[(size_t)r * n + c];
+            if (f == 0.0L) continue;
+            for (int j = 0; j < n; ++j) {
+                A[(size_t)r * n + j] -= f * A[(size_t)c * n + j];
+                Inv[(size_t)r * n + j] -= f * Inv[(size_t)c * n + j];
+            }
+        }
+    }
+    for (int s = 0; s < S; ++s) {
+        int first;
+        long double N[4];
+        basis_funs(t, k, n, us[s], first, N);
+        for (int j = 0; j < n; ++j) {
+            long double acc = 0.0L;
+            for (int q = 0; q <= k; ++q) acc += N[q] * Inv[(size_t)(first + q) * n + j];
+            M[(size_t)s * n + j] = (double)acc;
+        }
+    }
+    return MP_OK;
+}
+
+template <typename T> void to_vec(const double *src, size_t n, std::vector<T> &out)
+{
+    out.resize(n);
+    for (size_t i = 0; i < n; ++i) out[i] = (T)src[i];
+}
+
+template <typename T> int upload_scene(mp_ctx *ctx, int n, const double *cx, const double *cy, const double *cz,
+                                        const double *hx, const double *hy, const double *hz)
+{
+    std::vector<mp::BoxRec<T>> rec((size_t)std::max(n, 1));
+    for (int i = 0; i < n; ++i) {
+        rec[i].cx = (T)cx[i]; rec[i].cy = (T)cy[i]; rec[i].cz = (T)cz[i];
+        rec[i].hx = (T)hx[i]; rec[i].hy = (T)hy[i]; rec[i].hz = (T)hz[i];
+        rec[i].pad0 = T(0); rec[i].pad1 = T(0);
+    }
+    int rc = upload(ctx, ctx->boxes, rec.data(), (size_t)n * sizeof(mp::BoxRec<T>));
+    if (rc) return rc;
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));  // rec is a local
+    return MP_OK;
+}
+
+template <typename T> int upload_problem(mp_ctx *ctx, const mp_task *tasks)
+{
+    const mp_config &c = ctx->cfg;
+    std::vector<T> v;
+    to_vec<T>(ctx->basis.data(), ctx->basis.size(), v);
+    int rc = upload(ctx, ctx->d_M, v.data(), v.size() * sizeof(T));
+    if (rc) return rc;
+    std::vector<T> vy;
+    to_vec<T>(ctx->basis_yaw.data(), ctx->basis_yaw.size(), vy);
+    if ((rc = upload(ctx, ctx->d_My, vy.data(), vy.size() * sizeof(T)))) return rc;
+    std::vector<T> ts;
+    to_vec<T>(c.t_sched, (size_t)c.n_samples, ts);
+    if ((rc = upload(ctx, ctx->d_tsched, ts.data(), ts.size() * sizeof(T)))) return rc;
+    std::vector<mp::DevTask<T>> dt((size_t)ctx->n_tasks);
+    for (int i = 0; i < ctx->n_tasks; ++i) {
+        for (int j = 0; j < MP_MAX_CTRL; ++j) {
+            for (int a = 0; a < 3; ++a) dt[i].ctrl[j][a] = (T)tasks[i].ctrl[j][a];
+            dt[i].yaw_ctrl[j] = (T)tasks[i].yaw_ctrl[j];
+        }
+        for (int a = 0; a < 3; ++a) dt[i].normal[a] = (T)tasks[i].goal_normal[a];
+        dt[i].has_normal = tasks[i].has_goal_normal;
+        dt[i].yaw_inc = tasks[i].yaw_increasing;
+        dt[i].box_begin = tasks[i].box_begin;
+        dt[i].box_count = tasks[i].box_count;
+    }
+    if ((rc = upload(ctx, ctx->d_tasks, dt.data(), dt.size() * sizeof(mp::DevTask<T>)))) return rc;
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));  // locals go out of scope
+    return MP_OK;
+}
+
+template <typename T, int MODEL, bool GRAD>
+int launch_eval_k(mp_ctx *ctx, const mp::EvalArgs<T> &args, int wpb, int blocks, size_t lds_bytes)
+{
+    auto kern = mp::eval_kernel<T, MODEL, GRAD>;
+    if (lds_bytes > 65536)
+        HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                         (int)lds_bytes));
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(64 * wpb), lds_bytes, ctx->stream, args);
+    HIP_TRY(ctx, hipGetLastError());
+    return MP_OK;
+}
+
+template <typename T>
+int launch_eval(mp_ctx *ctx, long long n, const void *X, const int32_t *task_of, void *cost, void *terms, void *grad,
+                void *minc, uint8_t *flags, void *dist)
+{
+    const mp_config &c = ctx->cfg;
+    mp::EvalArgs<T> a{};
+    a.S = c.n_samples; a.C = c.n_ctrl; a.ff = c.first_free; a.nf = c.n_free; a.Cy = c.n_yaw_ctrl;
+    a.nyf = c.n_yaw_free; a.Sp = c.n_safe; a.last_cond = c.last_if_not_close; a.keep_n = c.keep_n;
+    a.use_pref = c.use_pref; a.tail_start = c.tail_start; a.use_goal_target = c.use_goal_target;
+    a.goal_tail_n = c.goal_tail_n; a.mask = c.term_mask;
+    a.lds_per_wave = mp::lds_units_per_wave(c.n_samples);
+    a.n_tasks = ctx->n_tasks;
+    for (int i = 0; i < MP_NTERMS; ++i) a.w[i] = (T)c.weights[i];
+    a.req = (T)c.required_clearance; a.pref = (T)c.preferred_clearance; a.appr_tgt = (T)c.approach_target;
+    a.goal_tgt = (T)c.goal_clearance_target; a.radius = (T)c.point_radius;
+    a.ax = (T)c.half_extents[0]; a.ay = (T)c.half_extents[1]; a.az = (T)c.half_extents[2];
+    a.idx_safe = (const int *)ctx->d_idx.p; a.amask = (const uint8_t *)ctx->d_mask.p;
+    a.M = (const T *)ctx->d_M.p; a.My = (const T *)ctx->d_My.p; a.tsched = (const T *)ctx->d_tsched.p;
+    a.tasks = (const mp::DevTask<T> *)ctx->d_tasks.p; a.boxes = (const mp::BoxRec<T> *)ctx->boxes.p;
+    a.X = (const T *)X; a.task_of = task_of; a.cpt = ctx->cands_per_task; a.n = n;
+    a.cost = (T *)cost; a.terms = (T *)terms; a.grad = (T *)grad; a.minc = (T *)minc; a.dist = (T *)dist;
+    a.flags = flags;
+
+    const size_t per_wave = (size_t)a.lds_per_wave * sizeof(T);
+    int wpb = (int)std::min<size_t>(4, std::max<size_t>(1, 65536 / per_wave));
+    const size_t lds_bytes = per_wave * wpb;
+    if (lds_bytes > ctx->max_lds)
+        return fail(ctx, MP_E_UNSUPPORTED, "n_samples_curve=%d needs %zu B of LDS per wave (limit %zu)", c.n_samples,
+                    per_wave, ctx->max_lds);
+    long long need = (n + wpb - 1) / wpb;
+    int blocks = (int)std::min<long long>(need, (long long)ctx->num_cu * 16);
+    if (blocks < 1) return MP_OK;
+    const bool g = grad != nullptr;
+    if (c.model == MP_MODEL_BOX)
+        return g ? launch_eval_k<T, 1, true>(ctx, a, wpb, blocks, lds_bytes)
+                 : launch_eval_k<T, 1, false>(ctx, a, wpb, blocks, lds_bytes);
+    return g ? launch_eval_k<T, 0, true>(ctx, a, wpb, blocks, lds_bytes)
+             : launch_eval_k<T, 0, false>(ctx, a, wpb, blocks, lds_bytes);
+}
+
+int check_ctx(mp_ctx *ctx)
+{
+    if (!ctx) return MP_E_ARG;
+    hipError_t e = hipSetDevice(ctx->device);
+    if (e != hipSuccess) return fail(ctx, MP_E_HIP, "hipSetDevice(%d): %s", ctx->device, hipGetErrorString(e));
+    return MP_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int mp_api_version(void) { return MP_API_VERSION; }
+
+const char *mp_last_error(const mp_ctx *ctx) { return ctx ? ctx->err : g_create_err; }
+
+int mp_create(int device_id, int dtype, mp_ctx **out)
+{
+    if (!out) return fail(nullptr, MP_E_ARG, "mp_create: out is NULL");
+    *out = nullptr;
+    if (dtype != MP_F64 && dtype != MP_F32) return fail(nullptr, MP_E_ARG, "mp_create: dtype must be MP_F64 or MP_F32");
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count <= 0)
+        return fail(nullptr, MP_E_HIP, "mp_create: no HIP device available (%s); this library has no CPU fallback",
+                    e != hipSuccess ? hipGetErrorString(e) : "device count is 0");
+    if (device_id < 0 || device_id >= count)
+        return fail(nullptr, MP_E_ARG, "mp_create: device_id %d out of range (0..%d)", device_id, count - 1);
+    mp_ctx *ctx = new mp_ctx();
+    ctx->device = device_id;
+    ctx->dtype = dtype;
+    auto bail = [&](const char *what, hipError_t err) {
+        fail(nullptr, MP_E_HIP, "mp_create: %s: %s", what, hipGetErrorString(err));
+        delete ctx;
+        return MP_E_HIP;
+    };
+    if ((e = hipSetDevice(device_id)) != hipSuccess) return bail("hipSetDevice", e);
+    hipDeviceProp_t prop;
+    if ((e = hipGetDeviceProperties(&prop, device_id)) != hipSuccess) return bail("hipGetDeviceProperties", e);
+    ctx->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    ctx->max_lds = prop.maxSharedMemoryPerMultiProcessor > 0 ? (size_t)prop.maxSharedMemoryPerMultiProcessor : 65536;
+    if ((e = hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking)) != hipSuccess) return bail("hipStreamCreate", e);
+    ctx->stream = ctx->own_stream;
+    if ((e = hipEventCreate(&ctx->ev0)) != hipSuccess) return bail("hipEventCreate", e);
+    if ((e = hipEventCreate(&ctx->ev1)) != hipSuccess) return bail("hipEventCreate", e);
+    *out = ctx;
+    return MP_OK;
+}
+
+int mp_destroy(mp_ctx *ctx)
+{
+    if (!ctx) return MP_OK;
+    hipSetDevice(ctx->device);
+    hipStreamSynchronize(ctx->stream);
+    DevBuf *bufs[] = {&ctx->boxes, &ctx->d_idx, &ctx->d_mask, &ctx->d_M, &ctx->d_My, &ctx->d_tsched, &ctx->d_tasks,
+                      &ctx->s_X, &ctx->s_taskof, &ctx->s_cost, &ctx->s_terms, &ctx->s_grad, &ctx->s_minc,
+                      &ctx->s_flags, &ctx->s_dist, &ctx->s_aux0, &ctx->s_aux1};
+    for (DevBuf *b : bufs)
+        if (b->p) hipFree(b->p);
+    if (ctx->ev0) hipEventDestroy(ctx->ev0);
+    if (ctx->ev1) hipEventDestroy(ctx->ev1);
+    if (ctx->own_stream) hipStreamDestroy(ctx->own_stream);
+    delete ctx;
+    return MP_OK;
+}
+
+int mp_set_stream(mp_ctx *ctx, void *hip_stream)
+{
+    int rc = check_ctx(ctx);
+    if (rc) return rc;
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
+    return MP_OK;
+}
+
+int mp_synchronize(mp_ctx *ctx)
+{
+    int rc = check_ctx(ctx);
+    if (rc) return rc;
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return MP_OK;
+}
+
+int mp_timer_start(mp_ctx *ctx)
+{
+    int rc = check_ctx(ctx);
+    if (rc) return rc;
+    HIP_TRY(ctx, hipEventRecord(ctx->ev0, ctx->stream));
+    return MP_OK;
+}
+
+int mp_timer_stop(mp_ctx *ctx, float *elapsed_ms)
+{
+    int rc = check_ctx(ctx);
+    if (rc) return rc;
+    if (!elapsed_ms) return fail(ctx, MP_E_ARG, "mp_timer_stop: elapsed_ms is NULL");
+    HIP_TRY(ctx, hipEventRecord(ctx->ev1, ctx->stream));
+    HIP_TRY(ctx, hipEventSynchronize(ctx->ev1));
+    HIP_TRY(ctx, hipEventElapsedTime(elapsed_ms, ctx->ev0, ctx->ev1));
+    return MP_OK;
+}
+
+int mp_set_scene(mp_ctx *ctx, int32_t n_boxes, const double *cx, const double *cy, const double *cz, const double *hx,
+                 const double *hy, const double *hz, const double *quat_xyzw)
+{
+    int rc = check_ctx(ctx);
+    if (rc) return rc;
+    if (n_boxes < 0) return fail(ctx, MP_E_ARG, "mp_set_scene: n_boxes < 0");
+    if (n_boxes > 0 && (!cx || !cy || !cz || !hx || !hy || !hz)) return fail(ctx, MP_E_ARG, "mp_set_scene: NULL array");
+    for (int i = 0; i < n_boxes; ++i) {
+        if (!(hx[i] >= 0.0 && hy[i] >= 0.0 && hz[i] >= 0.0))
+            return fail(ctx, MP_E_ARG, "mp_set_scene: box %d has a negative or NaN half extent", i);
+        if (quat_xyzw) {
+            const double *q = quat_xyzw + 4 * (size_t)i;
+            if (!(q[0] == 0.0 && q[1] == 0.0 && q[2] == 0.0 && std::fabs(q[3]) == 1.0))
+                return fail(ctx, MP_E_UNSUPPORTED, "mp_set_scene: box %d is rotated; static boxes must be axis aligned", i);
+        }
+    }
+    rc = ctx->dtype == MP_F64 ? upload_scene<double>(ctx, n_boxes, cx, cy, cz, hx, hy, hz)
+                              : upload_scene<float>(ctx, n_boxes, cx, cy, cz, hx, hy, hz);
+    if (rc) return rc;
+    ctx->n_boxes = n_boxes;
+    ctx->have_scene = true;
+    return MP_OK;
+}
+
+int mp_build_basis(int32_t n_ctrl, int32_t degree, int32_t n_samples, double *M)
+{
+    if (!M) return MP_E_ARG;
+    return build_basis(n_ctrl, degree, n_samples, M);
+}
+
+int mp_set_problem(mp_ctx *ctx, const mp_config *cfg, int32_t n_tasks, const mp_task *tasks)
+{
+    int rc = check_ctx(ctx);
+    if (rc) return rc;
+    if (!cfg || !tasks || n_tasks < 1) return fail(ctx, MP_E_ARG, "mp_set_problem: NULL cfg/tasks or n_tasks < 1");
+    if (!ctx->have_scene) return fail(ctx, MP_E_STATE, "mp_set_problem: call mp_set_scene first");
+    const mp_config &c = *cfg;
+    if (c.n_samples < 2 || c.n_samples > MP_MAX_SAMPLES) return fail(ctx, MP_E_ARG, "n_samples out of range");
+    if (c.n_ctrl < 4 || c.n_ctrl > MP_MAX_CTRL) return fail(ctx, MP_E_ARG, "n_ctrl must be in 4..%d", MP_MAX_CTRL);
+    if (c.n_yaw_ctrl < 2 || c.n_yaw_ctrl > MP_MAX_CTRL) return fail(ctx, MP_E_ARG, "n_yaw_ctrl must be in 2..%d", MP_MAX_CTRL);
+    if (c.n_free < 1 || c.first_free < 1 || c.first_free + c.n_free > c.n_ctrl - 1)
+        return fail(ctx, MP_E_ARG, "free waypoint rows [%d,%d) must lie strictly inside the %d waypoints", c.first_free,
+                    c.first_free + c.n_free, c.n_ctrl);
+    if (c.n_yaw_free != c.n_yaw_ctrl - 2) return fail(ctx, MP_E_ARG, "n_yaw_free must equal n_yaw_ctrl - 2");
+    if (c.model != MP_MODEL_POINT && c.model != MP_MODEL_BOX) return fail(ctx, MP_E_ARG, "unknown collision model");
+    if (c.n_safe < 1 || c.n_safe > c.n_samples) return fail(ctx, MP_E_ARG, "n_safe must be in 1..n_samples");
+    if (!c.idx_safe || !c.approach_mask || !c.t_sched) return fail(ctx, MP_E_ARG, "idx_safe / approach_mask / t_sched is NULL");
+    for (int k = 0; k < c.n_safe; ++k) {
+        if (c.idx_safe[k] < 0 || c.idx_safe[k] >= c.n_samples) return fail(ctx, MP_E_ARG, "idx_safe[%d] out of range", k);
+        if (k > 0 && c.idx_safe[k] <= c.idx_safe[k - 1]) return fail(ctx, MP_E_ARG, "idx_safe must be strictly increasing");
+    }
+    if (c.keep_n < 0 || c.tail_start < 0 || c.goal_tail_n < 0) return fail(ctx, MP_E_ARG, "negative window");
+    for (int i = 0; i < n_tasks; ++i) {
+        const mp_task &t = tasks[i];
+        if (t.box_begin < 0 || t.box_count < 0 || t.box_begin + t.box_count > ctx->n_boxes)
+            return fail(ctx, MP_E_ARG, "task %d: boxes [%d,%d) outside the scene (%d boxes)", i, t.box_begin,
+                        t.box_begin + t.box_count, ctx->n_boxes);
+    }
+    ctx->have_problem = false;
+    ctx->cfg = c;
+    ctx->n_tasks = n_tasks;
+    ctx->basis.assign((size_t)c.n_samples * c.n_ctrl, 0.0);
+    if (c.basis) std::memcpy(ctx->basis.data(), c.basis, ctx->basis.size() * sizeof(double));
+    else if ((rc = build_basis(c.n_ctrl, 3, c.n_samples, ctx->basis.data()))) return fail(ctx, rc, "basis construction failed");
+    ctx->basis_yaw.assign((size_t)c.n_samples * c.n_yaw_ctrl, 0.0);
+    if (c.basis_yaw) std::memcpy(ctx->basis_yaw.data(), c.basis_yaw, ctx->basis_yaw.size() * sizeof(double));
+    else if ((rc = build_basis(c.n_yaw_ctrl, std::min(3, c.n_yaw_ctrl - 1), c.n_samples, ctx->basis_yaw.data())))
+        return fail(ctx, rc, "yaw basis construction failed");
+    if ((rc = upload(ctx, ctx->d_idx, c.idx_safe, (size_t)c.n_safe * sizeof(int32_t)))) return rc;
+    if ((rc = upload(ctx, ctx->d_mask, c.approach_mask, (size_t)c.n_safe))) return rc;
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    rc = ctx->dtype == MP_F64 ? upload_problem<double>(ctx, tasks) : upload_problem<float>(ctx, tasks);
+    if (rc) return rc;
+    // the copied config must not keep caller pointers
+    ctx->cfg.idx_safe = nullptr; ctx->cfg.approach_mask = nullptr; ctx->cfg.basis = nullptr;
+    ctx->cfg.basis_yaw = nullptr; ctx->cfg.t_sched = nullptr;
+    ctx->have_problem = true;
+    return MP_OK;
+}
+
+int mp_get_basis(mp_ctx *ctx, double *M, double *M_yaw)
+{
+    if (!ctx) return MP_E_ARG;
+    if (!ctx->have_problem) return fail(ctx, MP_E_STATE, "mp_get_basis: no problem set");
+    if (M) std::memcpy(M, ctx->basis.data(), ctx->basis.size() * sizeof(double));
+    if (M_yaw) std::memcpy(M_yaw, ctx->basis_yaw.data(), ctx->basis_yaw.size() * sizeof(double));
+    return MP_OK;
+}
+
+int mp_set_cands_per_task(mp_ctx *ctx, int64_t cands_per_task)
+{
+    if (!ctx) return MP_E_ARG;
+    if (cands_per_task < 0) return fail(ctx, MP_E_ARG, "cands_per_task < 0");
+    ctx->cands_per_task = cands_per_task;
+    return MP_OK;
+}
+
+int mp_eval(mp_ctx *ctx, int64_t n, const void *X, const int32_t *task_of, void *cost, void *terms, void *grad,
+            void *min_clear, uint8_t *flags, void *dist, int mem)
+{
+    int rc = check_ctx(ctx);
+    if (rc) return rc;
+    if (!ctx->have_problem) return fail(ctx, MP_E_STATE, "mp_eval: call mp_set_scene and mp_set_problem first");
+    if (n < 0 || (n > 0 && (!X || !cost))) return fail(ctx, MP_E_ARG, "mp_eval: X and cost are required");
+    if (n == 0) return MP_OK;
+    if (mem != MP_MEM_HOST && mem != MP_MEM_DEVICE) return fail(ctx, MP_E_ARG, "mp_eval: unknown mem kind");
+    const mp_config &c = ctx->cfg;
+    const size_t es = esize(ctx);
+    const size_t D = (size_t)(3 * c.n_free + c.n_yaw_free);
+    if (!task_of && ctx->n_tasks > 1) {
+        if (ctx->cands_per_task <= 0) return fail(ctx, MP_E_ARG, "mp_eval: several tasks need task_of or mp_set_cands_per_task");
+        if ((n + ctx->cands_per_task - 1) / ctx->cands_per_task > ctx->n_tasks)
+            return fail(ctx, MP_E_ARG, "mp_eval: n exceeds n_tasks * cands_per_task");
+    }
+    if (!task_of && ctx->n_tasks == 1 && ctx->cands_per_task > 0 && n > ctx->cands_per_task)
+        return fail(ctx, MP_E_ARG, "mp_eval: n exceeds n_tasks * cands_per_task");
+
+    if (mem == MP_MEM_DEVICE) {
+        return ctx->dtype == MP_F64 ? launch_eval<double>(ctx, n, X, task_of, cost, terms, grad, min_clear, flags, dist)
+                                    : launch_eval<float>(ctx, n, X, task_of, cost, terms, grad, min_clear, flags, dist);
+    }
+    // host pointers: stage through device buffers owned by the context
+    if (task_of)
+        for (int64_t i = 0; i < n; ++i)
+            if (task_of[i] < 0 || task_of[i] >= ctx->n_tasks) return fail(ctx, MP_E_ARG, "mp_eval: task_of[%lld] out of range", (long long)i);
+    if ((rc = upload(ctx, ctx->s_X, X, (size_t)n * D * es))) return rc;
+    if (task_of && (rc = upload(ctx, ctx->s_taskof, task_of, (size_t)n * sizeof(int32_t)))) return rc;
+    if ((rc = reserve(ctx, ctx->s_cost, (size_t)n * es))) return rc;
+    if (terms && (rc = reserve(ctx, ctx->s_terms, (size_t)n * MP_NTERMS * es))) return rc;
+    if (grad && (rc = reserve(ctx, ctx->s_grad, (size_t)n * D * es))) return rc;
+    if (min_clear && (rc = reserve(ctx, ctx->s_minc, (size_t)n * es))) return rc;
+    if (flags && (rc = reserve(ctx, ctx->s_flags, (size_t)n))) return rc;
+    if (dist && (rc = reserve(ctx, ctx->s_dist, (size_t)n * c.n_safe * es))) return rc;
+    const int32_t *d_taskof = task_of ? (const int32_t *)ctx->s_taskof.p : nullptr;
+    void *d_terms = terms ? ctx->s_terms.p : nullptr, *d_grad = grad ? ctx->s_grad.p : nullptr;
+    void *d_minc = min_clear ? ctx->s_minc.p : nullptr, *d_dist = dist ? ctx->s_dist.p : nullptr;
+    uint8_t *d_flags = flags ? (uint8_t *)ctx->s_flags.p : nullptr;
+    rc = ctx->dtype == MP_F64
+             ? launch_eval<double>(ctx, n, ctx->s_X.p, d_taskof, ctx->s_cost.p, d_terms, d_grad, d_minc, d_flags, d_dist)
+             : launch_eval<float>(ctx, n, ctx->s_X.p, d_taskof, ctx->s_cost.p, d_terms, d_grad, d_minc, d_flags, d_dist);
+    if (rc) return rc;
+    HIP_TRY(ctx, hipMemcpyAsync(cost, ctx->s_cost.p, (size_t)n * es, hipMemcpyDeviceToHost, ctx->stream));
+    if (terms) HIP_TRY(ctx, hipMemcpyAsync(terms, d_terms, (size_t)n * MP_NTERMS * es, hipMemcpyDeviceToHost, ctx->stream));
+    if (grad) HIP_TRY(ctx, hipMemcpyAsync(grad, d_grad, (size_t)n * D * es, hipMemcpyDeviceToHost, ctx->stream));
+    if (min_clear) HIP_TRY(ctx, hipMemcpyAsync(min_clear, d_minc, (size_t)n * es, hipMemcpyDeviceToHost, ctx->stream));
+    if (flags) HIP_TRY(ctx, hipMemcpyAsync(flags, d_flags, (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
+    if (dist) HIP_TRY(ctx, hipMemcpyAsync(dist, d_dist, (size_t)n * c.n_safe * es, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return MP_OK;
+}
+
+static int sdf_common(mp_ctx *ctx, int64_t n, int32_t box_begin, int32_t box_count, int mem, const char *who)
+{
+    int rc = check_ctx(ctx);
+    if (rc) return rc;
+    if (!ctx->have_scene) return fail(ctx, MP_E_STATE, "%s: call mp_set_scene first", who);
+    if (n < 0) return fail(ctx, MP_E_ARG, "%s: n < 0", who);
+    if (box_begin < 0 || box_count < 0 || box_begin + box_count > ctx->n_boxes)
+        return fail(ctx, MP_E_ARG, "%s: boxes [%d,%d) outside the scene (%d boxes)", who, box_begin, box_begin + box_count,
+                    ctx->n_boxes);
+    if (mem != MP_MEM_HOST && mem != MP_MEM_DEVICE) return fail(ctx, MP_E_ARG, "%s: unknown mem kind", who);
+    return MP_OK;
+}
+
+int mp_point_sdf(mp_ctx *ctx, int64_t n, const void *pts, double point_radius, int32_t box_begin, int32_t box_count,
+                 void *out, int mem)
+{
+    int rc = sdf_common(ctx, n, box_begin, box_count, mem, "mp_point_sdf");
+    if (rc) return rc;
+    if (n == 0) return MP_OK;
+    if (!pts || !out) return fail(ctx, MP_E_ARG, "mp_point_sdf: NULL pointer");
+    const size_t es = esize(ctx);
+    const void *d_pts = pts;
+    void *d_out = out;
+    if (mem == MP_MEM_HOST) {
+        if ((rc = upload(ctx, ctx->s_aux0, pts, (size_t)n * 3 * es))) return rc;
+        if ((rc = reserve(ctx, ctx->s_aux1, (size_t)n * es))) return rc;
+        d_pts = ctx->s_aux0.p;
+        d_out = ctx->s_aux1.p;
+    }
+    int blocks = (int)std::min<long long>((n + 255) / 256, (long long)ctx->num_cu * 8);
+    if (ctx->dtype == MP_F64)
+        hipLaunchKernelGGL(mp::point_sdf_kernel<double>, dim3(blocks), dim3(256), 0, ctx->stream, (long long)n,
+                           (const double *)d_pts, (const mp::BoxRec<double> *)ctx->boxes.p + box_begin, box_count,
+                           point_radius, (double *)d_out);
+    else
+        hipLaunchKernelGGL(mp::point_sdf_kernel<float>, dim3(blocks), dim3(256), 0, ctx->stream, (long long)n,
+                           (const float *)d_pts, (const mp::BoxRec<float> *)ctx->boxes.p + box_begin, box_count,
+                           (float)point_radius, (float *)d_out);
+    HIP_TRY(ctx, hipGetLastError());
+    if (mem == MP_MEM_HOST) {
+        HIP_TRY(ctx, hipMemcpyAsync(out, d_out, (size_t)n * es, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    return MP_OK;
+}
+
+int mp_box_sdf(mp_ctx *ctx, int64_t n, const void *pos, const void *yaw_deg, const double size[3], int32_t box_begin,
+               int32_t box_count, void *out, int mem)
+{
+    int rc = sdf_common(ctx, n, box_begin, box_count, mem, "mp_box_sdf");
+    if (rc) return rc;
+    if (n == 0) return MP_OK;
+    if (!pos || !yaw_deg || !size || !out) return fail(ctx, MP_E_ARG, "mp_box_sdf: NULL pointer");
+    const size_t es = esize(ctx);
+    const void *d_pos = pos, *d_yaw = yaw_deg;
+    void *d_out = out;
+    if (mem == MP_MEM_HOST) {
+        // pos | yaw packed in one staging buffer
+        if ((rc = reserve(ctx, ctx->s_aux0, (size_t)n * 4 * es))) return rc;
+        if ((rc = reserve(ctx, ctx->s_aux1, (size_t)n * es))) return rc;
+        HIP_TRY(ctx, hipMemcpyAsync(ctx->s_aux0.p, pos, (size_t)n * 3 * es, hipMemcpyHostToDevice, ctx->stream));
+        HIP_TRY(ctx, hipMemcpyAsync((char *)ctx->s_aux0.p + (size_t)n * 3 * es, yaw_deg, (size_t)n * es,
+                                    hipMemcpyHostToDevice, ctx->stream));
+        d_pos = ctx->s_aux0.p;
+        d_yaw = (char *)ctx->s_aux0.p + (size_t)n * 3 * es;
+        d_out = ctx->s_aux1.p;
+    }
+    int blocks = (int)std::min<long long>((n + 255) / 256, (long long)ctx->num_cu * 8);
+    const double hx = 0.5 * size[0], hy = 0.5 * size[1], hz = 0.5 * size[2];
+    if (ctx->dtype == MP_F64)
+        hipLaunchKernelGGL(mp::box_sdf_kernel<double>, dim3(blocks), dim3(256), 0, ctx->stream, (long long)n,
+                           (const double *)d_pos, (const double *)d_yaw,
+                           (const mp::BoxRec<double> *)ctx->boxes.p + box_begin, box_count, hx, hy, hz, (double *)d_out);
+    else
+        hipLaunchKernelGGL(mp::box_sdf_kernel<float>, dim3(blocks), dim3(256), 0, ctx->stream, (long long)n,
+                           (const float *)d_pos, (const float *)d_yaw,
+                           (const mp::BoxRec<float> *)ctx->boxes.p + box_begin, box_count, (float)hx, (float)hy,
+                           (float)hz, (float *)d_out);
+    HIP_TRY(ctx, hipGetLastError());
+    if (mem == MP_MEM_HOST) {
+        HIP_TRY(ctx, hipMemcpyAsync(out, d_out, (size_t)n * es, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    return MP_OK;
+}
+
+}  // extern "C"

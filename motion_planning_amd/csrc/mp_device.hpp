@@ -1,0 +1,354 @@
+// mp_device.hpp — device-side math of the trajectory evaluation kernels (gfx950).
+//
+// Arithmetic contract (DESIGN.md §"Numerics"): IEEE + - * / sqrt, fma exactly where
+// written (mp_fma), no other contraction (the translation unit is compiled with
+// -ffp-contract=off), own sin/cos.  The CPU oracle follows the same contract, which is
+// what makes the collision / feasibility flags bit-exact between the two.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#pragma clang fp contract(off)
+
+namespace mp {
+
+template <typename T> struct Lim;
+template <> struct Lim<double> {
+    __device__ static double inf() { return __builtin_huge_val(); }
+    __device__ static double pio2_hi() { return 1.57079632679489655800e+00; }
+    __device__ static double pio2_lo() { return 6.12323399573676603587e-17; }
+};
+template <> struct Lim<float> {
+    __device__ static float inf() { return __builtin_huge_valf(); }
+    __device__ static float pio2_hi() { return 1.57079637050628662109e+00f; }
+    __device__ static float pio2_lo() { return -4.37113882867379288655e-08f; }
+};
+
+__device__ __forceinline__ double mp_fma(double a, double b, double c) { return __builtin_fma(a, b, c); }
+__device__ __forceinline__ float mp_fma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+__device__ __forceinline__ double mp_abs(double a) { return __builtin_fabs(a); }
+__device__ __forceinline__ float mp_abs(float a) { return __builtin_fabsf(a); }
+__device__ __forceinline__ double mp_sqrt(double a) { return __builtin_sqrt(a); }
+__device__ __forceinline__ float mp_sqrt(float a) { return __builtin_sqrtf(a); }
+__device__ __forceinline__ double mp_rint(double a) { return __builtin_rint(a); }
+__device__ __forceinline__ float mp_rint(float a) { return __builtin_rintf(a); }
+// max/min for finite operands (±0 may differ from a compare-select; callers only square
+// or compare the result)
+__device__ __forceinline__ double mp_max(double a, double b) { return __builtin_fmax(a, b); }
+__device__ __forceinline__ float mp_max(float a, float b) { return __builtin_fmaxf(a, b); }
+__device__ __forceinline__ double mp_min(double a, double b) { return __builtin_fmin(a, b); }
+__device__ __forceinline__ float mp_min(float a, float b) { return __builtin_fminf(a, b); }
+
+template <typename T> __device__ __forceinline__ T sgn(T v) { return v < T(0) ? T(-1) : T(1); }
+// np.maximum(0, v): NaN-propagating
+template <typename T> __device__ __forceinline__ T npmax0(T v) { return !(v <= T(0)) ? v : T(0); }
+
+// ---- sin/cos of the half yaw angle -------------------------------------------------
+// Cody-Waite reduction by pi/2 (two fma steps) + degree-13/12 minimax kernels on
+// [-pi/4, pi/4]; the coefficient set is the classic fdlibm one.  Same op sequence as the
+// oracle's orc_sincos.
+template <typename T> __device__ __forceinline__ void sincos_reduced(T h, T &sn, T &cs)
+{
+    const T TWO_OVER_PI = T(0.63661977236758134308);
+    const T PIO2_HI = Lim<T>::pio2_hi();
+    const T PIO2_LO = Lim<T>::pio2_lo();
+    const T S1 = T(-1.66666666666666324348e-01), S2 = T(8.33333333332248946124e-03),
+            S3 = T(-1.98412698298579493134e-04), S4 = T(2.75573137070700676789e-06),
+            S5 = T(-2.50507602534068634195e-08), S6 = T(1.58969099521155010221e-10);
+    const T C1 = T(4.16666666666666019037e-02), C2 = T(-1.38888888888741095749e-03),
+            C3 = T(2.48015872894767294178e-05), C4 = T(-2.75573143513906633035e-07),
+            C5 = T(2.08757232129817482790e-09), C6 = T(-1.13596475577881948265e-11);
+    T k = mp_rint(h * TWO_OVER_PI);
+    T r = mp_fma(-k, PIO2_HI, h);
+    r = mp_fma(-k, PIO2_LO, r);
+    int q = (int)((long long)k) & 3;
+    T z = r * r;
+    T ps = mp_fma(z, S6, S5);
+    ps = mp_fma(z, ps, S4);
+    ps = mp_fma(z, ps, S3);
+    ps = mp_fma(z, ps, S2);
+    ps = mp_fma(z, ps, S1);
+    T sr = mp_fma(r * z, ps, r);
+    T pc = mp_fma(z, C6, C5);
+    pc = mp_fma(z, pc, C4);
+    pc = mp_fma(z, pc, C3);
+    pc = mp_fma(z, pc, C2);
+    pc = mp_fma(z, pc, C1);
+    T cr = mp_fma(z * z, pc, mp_fma(T(-0.5), z, T(1.0)));
+    T a = (q & 1) ? cr : sr;  // sin candidates
+    T b = (q & 1) ? sr : cr;  // cos candidates
+    sn = (q & 2) ? -a : a;
+    cs = ((q + 1) & 2) ? -b : b;
+}
+
+// yaw in degrees -> (cos, sin) composed like yaw_deg_to_quat + quat_to_rot
+// (geom/spline_opt.py:37-40, geom/utils.py:3-14).
+template <typename T> __device__ __forceinline__ void yaw_rot(T yaw_deg, T &c, T &s)
+{
+    const T DEG2RAD = T(0.017453292519943295);
+    T h = T(0.5) * (yaw_deg * DEG2RAD);
+    T zq, wq;
+    sincos_reduced(h, zq, wq);
+    c = T(1.0) - T(2.0) * (zq * zq);
+    s = T(2.0) * (wq * zq);
+}
+
+// ---- box model -----------------------------------------------------------------------
+template <typename T> struct Pose {
+    T px, py, pz, c, s;
+    T ex, ey, u1x, u1y, u2x, u2y;
+};
+
+template <typename T>
+__device__ __forceinline__ void pose_setup(Pose<T> &p, T px, T py, T pz, T c, T s, T ax, T ay)
+{
+    p.px = px; p.py = py; p.pz = pz; p.c = c; p.s = s;
+    T ac = mp_abs(c), as = mp_abs(s);
+    p.ex = mp_fma(as, ay, ac * ax);
+    p.ey = mp_fma(ac, ay, as * ax);
+    p.u1x = mp_fma(-s, ay, c * ax);
+    p.u1y = mp_fma(c, ay, s * ax);
+    p.u2x = mp_fma(s, ay, c * ax);
+    p.u2y = mp_fma(-c, ay, s * ax);
+}
+
+template <typename T> __device__ __forceinline__ T rect_d2(T x, T y, T hx, T hy)
+{
+    T qx = mp_abs(x) - hx, qy = mp_abs(y) - hy;
+    T mx = mp_max(qx, T(0)), my = mp_max(qy, T(0));
+    return mp_fma(my, my, mx * mx);
+}
+
+// One (pose, box) pair.  sep == true: v = squared distance; sep == false: v = minus the
+// minimum SAT overlap (<= 0).
+template <typename T> struct BoxRec { T cx, cy, cz, hx, hy, hz, pad0, pad1; };
+
+template <typename T> struct PairOut {
+    T gx, gy, gax, gay, gz, gsat, dx, dy, dz, lx, ly, w1x, w1y, w2x, w2y;
+};
+
+template <typename T>
+__device__ __forceinline__ void pair_axes(const Pose<T> &p, T ax, T ay, T az, T bcx, T bcy, T bcz, T hbx,
+                                           T hby, T hbz, PairOut<T> &o)
+{
+    T c = p.c, s = p.s, ac = mp_abs(c), as = mp_abs(s);
+    o.dx = p.px - bcx; o.dy = p.py - bcy; o.dz = p.pz - bcz;
+    o.gz = mp_abs(o.dz) - (az + hbz);
+    o.gx = mp_abs(o.dx) - (hbx + p.ex);
+    o.gy = mp_abs(o.dy) - (hby + p.ey);
+    o.lx = mp_fma(s, o.dy, c * o.dx);
+    o.ly = mp_fma(c, o.dy, -(s * o.dx));
+    T rbx = mp_fma(as, hby, ac * hbx);
+    T rby = mp_fma(ac, hby, as * hbx);
+    o.gax = mp_abs(o.lx) - (ax + rbx);
+    o.gay = mp_abs(o.ly) - (ay + rby);
+    o.gsat = mp_max(mp_max(o.gx, o.gy), mp_max(o.gax, o.gay));
+    o.w1x = mp_fma(s, hby, c * hbx);
+    o.w1y = mp_fma(c, hby, -(s * hbx));
+    o.w2x = mp_fma(-s, hby, c * hbx);
+    o.w2y = -mp_fma(c, hby, s * hbx);
+}
+
+// scene value for one pose: min over boxes (boxes pointer and nb are wave-uniform)
+template <typename T>
+__device__ __forceinline__ T pose_distance(const Pose<T> &p, T ax, T ay, T az, const BoxRec<T> *__restrict__ boxes,
+                                            int nb, int &arg_box)
+{
+    T sep2 = Lim<T>::inf(), pen = Lim<T>::inf();
+    int isep = -1, ipen = -1;
+    for (int b = 0; b < nb; ++b) {
+        const BoxRec<T> bx = boxes[b];
+        PairOut<T> o;
+        pair_axes(p, ax, ay, az, bx.cx, bx.cy, bx.cz, bx.hx, bx.hy, bx.hz, o);
+        const bool xy_sep = o.gsat > T(0);
+        const bool separated = xy_sep || o.gz > T(0);
+        T dxy2 = T(0);
+        if (__builtin_amdgcn_ballot_w64(xy_sep)) {
+            T v = rect_d2(o.dx + p.u1x, o.dy + p.u1y, bx.hx, bx.hy);
+            v = mp_min(v, rect_d2(o.dx - p.u1x, o.dy - p.u1y, bx.hx, bx.hy));
+            v = mp_min(v, rect_d2(o.dx + p.u2x, o.dy + p.u2y, bx.hx, bx.hy));
+            v = mp_min(v, rect_d2(o.dx - p.u2x, o.dy - p.u2y, bx.hx, bx.hy));
+            v = mp_min(v, rect_d2(o.lx - o.w1x, o.ly - o.w1y, ax, ay));
+            v = mp_min(v, rect_d2(o.lx + o.w1x, o.ly + o.w1y, ax, ay));
+            v = mp_min(v, rect_d2(o.lx - o.w2x, o.ly - o.w2y, ax, ay));
+            v = mp_min(v, rect_d2(o.lx + o.w2x, o.ly + o.w2y, ax, ay));
+            dxy2 = xy_sep ? v : T(0);
+        }
+        T zs = mp_max(o.gz, T(0));
+        T v2 = mp_fma(zs, zs, dxy2);
+        T pn = mp_max(o.gsat, o.gz);
+        bool bs = separated && (v2 < sep2);
+        bool bp = !separated && (pn < pen);
+        sep2 = bs ? v2 : sep2;
+        isep = bs ? b : isep;
+        pen = bp ? pn : pen;
+        ipen = bp ? b : ipen;
+    }
+    if (ipen >= 0) { arg_box = ipen; return pen; }
+    arg_box = isep;
+    return mp_sqrt(sep2);
+}
+
+// d(pair)/d(px,py,pz,theta[rad]) for the deciding box (mirrors the oracle's pair_grad)
+template <typename T>
+__device__ __forceinline__ void pair_grad(const Pose<T> &p, T ax, T ay, T az, const BoxRec<T> bx, T &g0, T &g1,
+                                           T &g2, T &g3)
+{
+    PairOut<T> o;
+    pair_axes(p, ax, ay, az, bx.cx, bx.cy, bx.cz, bx.hx, bx.hy, bx.hz, o);
+    const T c = p.c, s = p.s;
+    g0 = g1 = g2 = g3 = T(0);
+    const bool xy_sep = o.gsat > T(0);
+    if (xy_sep || o.gz > T(0)) {
+        T v[8];
+        v[0] = rect_d2(o.dx + p.u1x, o.dy + p.u1y, bx.hx, bx.hy);
+        v[1] = rect_d2(o.dx - p.u1x, o.dy - p.u1y, bx.hx, bx.hy);
+        v[2] = rect_d2(o.dx + p.u2x, o.dy + p.u2y, bx.hx, bx.hy);
+        v[3] = rect_d2(o.dx - p.u2x, o.dy - p.u2y, bx.hx, bx.hy);
+        v[4] = rect_d2(o.lx - o.w1x, o.ly - o.w1y, ax, ay);
+        v[5] = rect_d2(o.lx + o.w1x, o.ly + o.w1y, ax, ay);
+        v[6] = rect_d2(o.lx - o.w2x, o.ly - o.w2y, ax, ay);
+        v[7] = rect_d2(o.lx + o.w2x, o.ly + o.w2y, ax, ay);
+        T dxy2 = v[0];
+        int f = 0;
+#pragma unroll
+        for (int i = 1; i < 8; ++i) {
+            bool lt = v[i] < dxy2;
+            dxy2 = lt ? v[i] : dxy2;
+            f = lt ? i : f;
+        }
+        if (!xy_sep) dxy2 = T(0);
+        T zs = mp_max(o.gz, T(0));
+        T d = mp_sqrt(mp_fma(zs, zs, dxy2));
+        if (!(d > T(0))) return;
+        if (o.gz > T(0)) g2 = sgn(o.dz) * o.gz / d;
+        if (!xy_sep) return;
+        if (f < 4) {
+            T rx = (f < 2) ? p.u1x : p.u2x, ry = (f < 2) ? p.u1y : p.u2y;
+            if (f & 1) { rx = -rx; ry = -ry; }
+            T X = o.dx + rx, Y = o.dy + ry;
+            T qx = mp_abs(X) - bx.hx, qy = mp_abs(Y) - bx.hy;
+            T mx = qx > T(0) ? sgn(X) * qx : T(0);
+            T my = qy > T(0) ? sgn(Y) * qy : T(0);
+            g0 = mx / d;
+            g1 = my / d;
+            g3 = (my * rx - mx * ry) / d;
+        } else {
+            T wx = (f < 6) ? o.w1x : o.w2x, wy = (f < 6) ? o.w1y : o.w2y;
+            if (!(f & 1)) { wx = -wx; wy = -wy; }
+            T tx = o.lx + wx, ty = o.ly + wy;
+            T qx = mp_abs(tx) - ax, qy = mp_abs(ty) - ay;
+            T mx = qx > T(0) ? sgn(tx) * qx : T(0);
+            T my = qy > T(0) ? sgn(ty) * qy : T(0);
+            g0 = (c * mx - s * my) / d;
+            g1 = (s * mx + c * my) / d;
+            g3 = (mx * ty - my * tx) / d;
+        }
+    } else {
+        int a = 0;
+        T best = o.gx;
+        if (o.gy > best) { best = o.gy; a = 1; }
+        if (o.gax > best) { best = o.gax; a = 2; }
+        if (o.gay > best) { best = o.gay; a = 3; }
+        if (o.gz > best) { best = o.gz; a = 4; }
+        T sc = sgn(c), ss = sgn(s);
+        if (a == 0) {
+            g0 = sgn(o.dx);
+            g3 = -(-sc * s * ax + ss * c * ay);
+        } else if (a == 1) {
+            g1 = sgn(o.dy);
+            g3 = -(ss * c * ax - sc * s * ay);
+        } else if (a == 2) {
+            T sl = sgn(o.lx);
+            g0 = sl * c; g1 = sl * s;
+            g3 = sl * o.ly - (-sc * s * bx.hx + ss * c * bx.hy);
+        } else if (a == 3) {
+            T sl = sgn(o.ly);
+            g0 = -sl * s; g1 = sl * c;
+            g3 = -sl * o.lx - (ss * c * bx.hx - sc * s * bx.hy);
+        } else {
+            g2 = sgn(o.dz);
+        }
+    }
+}
+
+// ---- point model -----------------------------------------------------------------------
+template <typename T>
+__device__ __forceinline__ T point_distance(T px, T py, T pz, const BoxRec<T> *__restrict__ boxes, int nb, T radius,
+                                             int &arg_box)
+{
+    T out2 = Lim<T>::inf(), in = Lim<T>::inf();
+    int iout = -1, iin = -1;
+    for (int b = 0; b < nb; ++b) {
+        const BoxRec<T> bx = boxes[b];
+        T qx = mp_abs(px - bx.cx) - bx.hx, qy = mp_abs(py - bx.cy) - bx.hy, qz = mp_abs(pz - bx.cz) - bx.hz;
+        bool outside = qx > T(0) || qy > T(0) || qz > T(0);
+        T mx = mp_max(qx, T(0)), my = mp_max(qy, T(0)), mz = mp_max(qz, T(0));
+        T v = mp_fma(mz, mz, mp_fma(my, my, mx * mx));
+        T m = mp_max(mp_max(qx, qy), qz);
+        bool bo = outside && v < out2;
+        bool bi = !outside && m < in;
+        out2 = bo ? v : out2;
+        iout = bo ? b : iout;
+        in = bi ? m : in;
+        iin = bi ? b : iin;
+    }
+    if (iin >= 0) { arg_box = iin; return in; }
+    arg_box = iout;
+    return mp_sqrt(out2) - radius;
+}
+
+template <typename T>
+__device__ __forceinline__ void point_grad(T px, T py, T pz, const BoxRec<T> bx, T &g0, T &g1, T &g2)
+{
+    T ex = px - bx.cx, ey = py - bx.cy, ez = pz - bx.cz;
+    T qx = mp_abs(ex) - bx.hx, qy = mp_abs(ey) - bx.hy, qz = mp_abs(ez) - bx.hz;
+    g0 = g1 = g2 = T(0);
+    if (qx > T(0) || qy > T(0) || qz > T(0)) {
+        T mx = mp_max(qx, T(0)), my = mp_max(qy, T(0)), mz = mp_max(qz, T(0));
+        T d = mp_sqrt(mp_fma(mz, mz, mp_fma(my, my, mx * mx)));
+        if (!(d > T(0))) return;
+        g0 = sgn(ex) * mx / d; g1 = sgn(ey) * my / d; g2 = sgn(ez) * mz / d;
+    } else {
+        int a = 0;
+        T best = qx;
+        if (qy > best) { best = qy; a = 1; }
+        if (qz > best) { best = qz; a = 2; }
+        T sg = sgn(a == 0 ? ex : (a == 1 ? ey : ez));
+        g0 = a == 0 ? sg : T(0); g1 = a == 1 ? sg : T(0); g2 = a == 2 ? sg : T(0);
+    }
+}
+
+// ---- wave helpers ----------------------------------------------------------------------
+__device__ __forceinline__ void wave_lds_sync()
+{
+    // the 64 lanes of one wave exchange data through their private LDS slice: LDS
+    // operations of a wave complete in issue order, this only pins the compiler's order
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+__device__ __forceinline__ double wave_sum(double v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_sum(float v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+template <typename T> __device__ __forceinline__ T wave_min(T v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        T o = __shfl_xor(v, off, 64);
+        v = o < v ? o : v;
+    }
+    return v;
+}
+
+}  // namespace mp

@@ -1,0 +1,504 @@
+// mp_kernels.hpp — the trajectory evaluation kernels (gfx950 / CDNA4).
+//
+// Mapping: ONE 64-lane wavefront per candidate trajectory.  The S spline samples live on
+// the lanes (sample s on lane s % 64); the static boxes are wave-uniform and streamed
+// through the scalar data path; all cross-sample stencils (np.gradient, second
+// differences, tail windows) go through a per-wave LDS slice; per-trajectory sums use
+// wavefront shuffles.  No MFMA: the spline product is a C<=16 term contraction per sample.
+#pragma once
+#include "mp_device.hpp"
+
+namespace mp {
+
+constexpr int kMaxCtrl = 16;
+constexpr int kNTerms = 15;
+
+template <typename T> struct DevTask {
+    T ctrl[kMaxCtrl][3];
+    T yaw_ctrl[kMaxCtrl];
+    T normal[3];
+    int has_normal, yaw_inc, box_begin, box_count;
+};
+
+template <typename T> struct EvalArgs {
+    int S, C, ff, nf, Cy, nyf, Sp, last_cond, keep_n, use_pref, tail_start, use_goal_target, goal_tail_n;
+    unsigned mask;
+    int lds_per_wave;  // in units of T
+    int n_tasks;
+    T w[kNTerms];
+    T req, pref, appr_tgt, goal_tgt, radius, ax, ay, az;
+    const int *idx_safe;
+    const uint8_t *amask;
+    const T *M;
+    const T *My;
+    const T *tsched;
+    const DevTask<T> *tasks;
+    const BoxRec<T> *boxes;
+    const T *X;
+    const int *task_of;
+    long long cpt;
+    long long n;
+    T *cost, *terms, *grad, *minc, *dist;
+    uint8_t *flags;
+};
+
+// LDS slice of one wave, in units of T.  Layout (S = samples):
+//   W[64] | P[3][S] YAW[S] | GP[3][S] GY[S] | D[S] GD[S] | CC[S] SS[S] | D1[3][S] A1[3][S] A2[3][S] | ARG[S] (int)
+__host__ __device__ inline int lds_units_per_wave(int S) { return 64 + 22 * S; }
+
+template <typename T, int MODEL, bool GRAD>
+__global__ void __launch_bounds__(256) eval_kernel(const EvalArgs<T> a)
+{
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    const int lane = threadIdx.x & 63;
+    const int wib = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int wpb = (int)(blockDim.x >> 6);
+    const int S = a.S, C = a.C, Cy = a.Cy, nf = a.nf, ff = a.ff, nyf = a.nyf;
+    const int D = 3 * nf + nyf;
+    T *base = reinterpret_cast<T *>(smem_raw) + (size_t)wib * a.lds_per_wave;
+    T *W = base;
+    T *P0 = W + 64, *P1 = P0 + S, *P2 = P1 + S, *YW = P2 + S;
+    T *G0 = YW + S, *G1 = G0 + S, *G2 = G1 + S, *GY = G2 + S;
+    T *Dd = GY + S, *GD = Dd + S;
+    T *CC = GD + S, *SS = CC + S;
+    T *D1x = SS + S, *D1y = D1x + S, *D1z = D1y + S;
+    T *A1x = D1z + S, *A1y = A1x + S, *A1z = A1y + S;
+    T *A2x = A1z + S, *A2y = A2x + S, *A2z = A2y + S;
+    int *ARG = reinterpret_cast<int *>(A2z + S);
+    const unsigned mask = a.mask;
+    const T du = T(1) / (T)(S - 1);
+    const T inv_du = T(1);  // (unused placeholder to keep the reference's division form)
+    (void)inv_du;
+
+    for (long long cand = (long long)blockIdx.x * wpb + wib; cand < a.n; cand += (long long)gridDim.x * wpb) {
+        long long tl = a.task_of ? (long long)a.task_of[cand] : (a.cpt > 0 ? cand / a.cpt : 0);
+        const int t = __builtin_amdgcn_readfirstlane((int)tl);
+        const DevTask<T> &tk = a.tasks[t];
+        const T *x = a.X + cand * D;
+        const int nb = tk.box_count;
+        const BoxRec<T> *boxes = a.boxes + tk.box_begin;
+
+        // ---- waypoint table W[j][0..2] = position rows, W[j][3] = yaw controls ----
+        {
+            const int rows = C > Cy ? C : Cy;
+            for (int i = lane; i < rows * 4; i += 64) {
+                const int j = i >> 2, col = i & 3;
+                T v = T(0);
+                if (col < 3) {
+                    if (j < C) v = (j >= ff && j < ff + nf) ? x[3 * (j - ff) + col] : tk.ctrl[j][col];
+                } else if (j < Cy) {
+                    v = (j >= 1 && j <= nyf) ? x[3 * nf + (j - 1)] : tk.yaw_ctrl[j];
+                }
+                W[i] = v;
+            }
+        }
+        wave_lds_sync();
+
+        // ---- spline samples Q = M W (fixed fma chain over the waypoints) ----
+        for (int s = lane; s < S; s += 64) {
+            const T *m = a.M + (size_t)s * C;
+            T m0 = m[0];
+            T px = m0 * W[0], py = m0 * W[1], pz = m0 * W[2];
+            for (int j = 1; j < C; ++j) {
+                T mj = m[j];
+                px = mp_fma(mj, W[4 * j + 0], px);
+                py = mp_fma(mj, W[4 * j + 1], py);
+                pz = mp_fma(mj, W[4 * j + 2], pz);
+            }
+            const T *my = a.My + (size_t)s * Cy;
+            T yw = my[0] * W[3];
+            for (int j = 1; j < Cy; ++j) yw = mp_fma(my[j], W[4 * j + 3], yw);
+            P0[s] = px; P1[s] = py; P2[s] = pz; YW[s] = yw;
+            if (GRAD) { G0[s] = T(0); G1[s] = T(0); G2[s] = T(0); GY[s] = T(0); }
+        }
+        wave_lds_sync();
+
+        // ---- per-sample geometric terms, pass 1 ----
+        T t_len = T(0), t_ys = T(0), t_mono = T(0), t_sched = T(0), t_curv = T(0);
+        const T y0 = tk.yaw_ctrl[0], y1 = tk.yaw_ctrl[Cy - 1];
+        for (int s = lane; s < S; s += 64) {
+            const T px = P0[s], py = P1[s], pz = P2[s], yw = YW[s];
+            if (s + 1 < S) {
+                T ex = P0[s + 1] - px, ey = P1[s + 1] - py, ez = P2[s + 1] - pz;
+                t_len += mp_sqrt(ex * ex + ey * ey + ez * ez);
+                T dy = YW[s + 1] - yw;
+                T e = npmax0(tk.yaw_inc ? -dy : dy);
+                t_mono += e * e;
+            }
+            if (s + 2 < S) {
+                T e = yw - T(2) * YW[s + 1] + YW[s + 2];
+                t_ys += e * e;
+            }
+            {
+                T target = y0 + (y1 - y0) * a.tsched[s];
+                T e = yw - target;
+                t_sched += e * e;
+            }
+            if (S >= 3) {  // np.gradient(P, du)
+                T gx, gy, gz;
+                if (s == 0) {
+                    gx = (P0[1] - px) / du; gy = (P1[1] - py) / du; gz = (P2[1] - pz) / du;
+                } else if (s == S - 1) {
+                    gx = (px - P0[s - 1]) / du; gy = (py - P1[s - 1]) / du; gz = (pz - P2[s - 1]) / du;
+                } else {
+                    const T h2 = T(2) * du;
+                    gx = (P0[s + 1] - P0[s - 1]) / h2; gy = (P1[s + 1] - P1[s - 1]) / h2;
+                    gz = (P2[s + 1] - P2[s - 1]) / h2;
+                }
+                D1x[s] = gx; D1y[s] = gy; D1z[s] = gz;
+            }
+        }
+        wave_lds_sync();
+        // ---- curvature, pass 2 (second np.gradient) ----
+        if ((mask & (1u << 1)) && S >= 3) {
+            const T eps = T(1e-9);
+            for (int s = lane; s < S; s += 64) {
+                const T v1x = D1x[s], v1y = D1y[s], v1z = D1z[s];
+                T v2x, v2y, v2z;
+                if (s == 0) {
+                    v2x = (D1x[1] - v1x) / du; v2y = (D1y[1] - v1y) / du; v2z = (D1z[1] - v1z) / du;
+                } else if (s == S - 1) {
+                    v2x = (v1x - D1x[s - 1]) / du; v2y = (v1y - D1y[s - 1]) / du; v2z = (v1z - D1z[s - 1]) / du;
+                } else {
+                    const T h2 = T(2) * du;
+                    v2x = (D1x[s + 1] - D1x[s - 1]) / h2; v2y = (D1y[s + 1] - D1y[s - 1]) / h2;
+                    v2z = (D1z[s + 1] - D1z[s - 1]) / h2;
+                }
+                T speed = mp_sqrt(v1x * v1x + v1y * v1y + v1z * v1z);
+                T cx = v1y * v2z - v1z * v2y, cy = v1z * v2x - v1x * v2z, cz = v1x * v2y - v1y * v2x;
+                T cn = mp_sqrt(cx * cx + cy * cy + cz * cz);
+                T sp = speed > eps ? speed : eps;
+                T sp3 = sp * sp * sp;
+                T kappa = cn / sp3;
+                t_curv += (kappa * kappa) * speed;
+                if (GRAD) {
+                    T sp6 = sp3 * sp3;
+                    T k = a.w[1] * du;
+                    T f2 = k * T(2) * speed / sp6;
+                    T gcx = f2 * cx, gcy = f2 * cy, gcz = f2 * cz;
+                    T gs = cn * cn / sp6;
+                    if (speed > eps) gs += T(-6) * cn * cn * speed / (sp6 * sp);
+                    gs *= k;
+                    T g1x = v2y * gcz - v2z * gcy, g1y = v2z * gcx - v2x * gcz, g1z = v2x * gcy - v2y * gcx;
+                    T g2x = gcy * v1z - gcz * v1y, g2y = gcz * v1x - gcx * v1z, g2z = gcx * v1y - gcy * v1x;
+                    if (speed > T(0)) {
+                        T q = gs / speed;
+                        g1x += q * v1x; g1y += q * v1y; g1z += q * v1z;
+                    }
+                    A1x[s] = g1x; A1y[s] = g1y; A1z[s] = g1z;
+                    A2x[s] = g2x; A2y[s] = g2y; A2z[s] = g2z;
+                }
+            }
+        } else if (GRAD) {
+            for (int s = lane; s < S; s += 64) {
+                A1x[s] = T(0); A1y[s] = T(0); A1z[s] = T(0);
+                A2x[s] = T(0); A2y[s] = T(0); A2z[s] = T(0);
+            }
+        }
+
+        // ---- clearance profile d_safe ----
+        int Sp = a.Sp;
+        for (int k = lane; k < Sp; k += 64) {
+            const int s = a.idx_safe[k];
+            int arg = -1;
+            T d;
+            if (MODEL == 1) {
+                T c, sn;
+                yaw_rot(YW[s], c, sn);
+                Pose<T> ps;
+                pose_setup(ps, P0[s], P1[s], P2[s], c, sn, a.ax, a.ay);
+                d = pose_distance(ps, a.ax, a.ay, a.az, boxes, nb, arg);
+                CC[k] = c; SS[k] = sn;
+            } else {
+                d = point_distance(P0[s], P1[s], P2[s], boxes, nb, a.radius, arg);
+            }
+            Dd[k] = d;
+            ARG[k] = arg;
+            if (a.dist) a.dist[cand * a.Sp + k] = d;
+        }
+        wave_lds_sync();
+        if (a.last_cond && Sp >= 2) {  // P[::k] + conditional last sample (spline_opt.py:802-805)
+            const int sa = a.idx_safe[Sp - 2], sb = S - 1;
+            bool close = mp_abs(P0[sa] - P0[sb]) <= T(1e-8) + T(1e-5) * mp_abs(P0[sb]);
+            close = close && (mp_abs(P1[sa] - P1[sb]) <= T(1e-8) + T(1e-5) * mp_abs(P1[sb]));
+            close = close && (mp_abs(P2[sa] - P2[sb]) <= T(1e-8) + T(1e-5) * mp_abs(P2[sb]));
+            if (close) Sp -= 1;
+        }
+
+        // ---- clearance terms (and d cost / d d_k) ----
+        T t_safe = T(0), t_pref = T(0), t_reb = T(0), t_gc = T(0), t_gt = T(0), t_ac = T(0), t_acol = T(0);
+        T mc = Lim<T>::inf();
+        for (int k = lane; k < Sp; k += 64) {
+            const T d = Dd[k];
+            mc = d < mc ? d : mc;
+            T gd = T(0);
+            if (mask & (1u << 3)) {
+                T e = npmax0(a.req - d);
+                t_safe += e * e;
+                gd -= a.w[3] * T(2) * e;
+            }
+            if ((mask & (1u << 4)) && a.use_pref && k < a.keep_n) {
+                T e = npmax0(a.pref - d);
+                t_pref += e * e;
+                gd -= a.w[4] * T(2) * e;
+            }
+            if (mask & (1u << 5)) {
+                if (k >= a.tail_start && k + 1 < Sp) {
+                    T e = npmax0(Dd[k + 1] - d);
+                    t_reb += e * e;
+                    gd -= a.w[5] * T(2) * e;
+                }
+                if (k - 1 >= a.tail_start && k - 1 >= 0) {
+                    T e = npmax0(d - Dd[k - 1]);
+                    gd += a.w[5] * T(2) * e;
+                }
+            }
+            if (k == Sp - 1) {
+                if (mask & (1u << 6)) {
+                    T e = d - a.pref;
+                    e = e > T(0) ? e : T(0);
+                    t_gc = e * e;
+                    gd += a.w[6] * T(2) * e;
+                }
+                if ((mask & (1u << 7)) && a.use_goal_target) {
+                    T e = d - a.goal_tgt;
+                    t_gt = e * e;
+                    gd += a.w[7] * T(2) * e;
+                }
+            }
+            if (a.amask[k]) {
+                if (mask & (1u << 8)) {
+                    T e = npmax0(a.appr_tgt - d);
+                    t_ac += e * e;
+                    gd -= a.w[8] * T(2) * e;
+                }
+                if (mask & (1u << 9)) {
+                    T e = npmax0(-d);
+                    t_acol += e * e;
+                    gd -= a.w[9] * T(2) * e;
+                }
+            }
+            if (GRAD) GD[k] = gd;
+        }
+
+        // ---- small closed-form terms, computed redundantly by every lane ----
+        T t_via = T(0), t_ydev = T(0), t_gn = T(0);
+        if (mask & (1u << 10))
+            for (int j = 0; j < nf; ++j)
+                for (int c3 = 0; c3 < 3; ++c3) {
+                    T e = W[4 * (ff + j) + c3] - tk.ctrl[ff + j][c3];
+                    t_via += e * e;
+                }
+        if (mask & (1u << 11))
+            for (int j = 0; j < Cy; ++j) {
+                T e = W[4 * j + 3] - tk.yaw_ctrl[j];
+                t_ydev += e * e;
+            }
+        // goal approach alignment: v = P[S-1] - P[first] (telescoped sum of the tail diffs)
+        T gnx = T(0), gny = T(0), gnz = T(0);
+        int gn_first = S - a.goal_tail_n;
+        gn_first = gn_first < 0 ? 0 : gn_first;
+        if ((mask & (1u << 14)) && tk.has_normal && S >= 3 && gn_first < S - 1) {
+            T vx = P0[S - 1] - P0[gn_first], vy = P1[S - 1] - P1[gn_first], vz = P2[S - 1] - P2[gn_first];
+            T n = mp_sqrt(vx * vx + vy * vy + vz * vz);
+            if (!(n < T(1e-12))) {
+                T ux = vx / n, uy = vy / n, uz = vz / n;
+                if (ux != T(0) || uy != T(0) || uz != T(0)) {
+                    const T sx = tk.normal[0], sy = tk.normal[1], sz = tk.normal[2];
+                    T c = ux * -sx + uy * -sy + uz * -sz;
+                    T cc = c < T(-1) ? T(-1) : (c > T(1) ? T(1) : c);
+                    T e = T(1) - cc;
+                    t_gn = e * e;
+                    if (GRAD && c > T(-1) && c < T(1)) {
+                        T us = ux * sx + uy * sy + uz * sz;
+                        T k = a.w[14] * T(-2) * e;
+                        gnx = k * -(sx - ux * us) / n;
+                        gny = k * -(sy - uy * us) / n;
+                        gnz = k * -(sz - uz * us) / n;
+                    }
+                }
+            }
+        }
+
+        // ---- reductions over the wave and outputs ----
+        T term[kNTerms];
+        term[0] = (mask & 1u) ? wave_sum(t_len) : T(0);
+        term[1] = ((mask & 2u) && S >= 3) ? wave_sum(t_curv) * du : T(0);
+        term[2] = ((mask & 4u) && S >= 3) ? wave_sum(t_ys) : T(0);
+        term[3] = wave_sum(t_safe);
+        term[4] = wave_sum(t_pref);
+        term[5] = wave_sum(t_reb);
+        term[6] = wave_sum(t_gc);
+        term[7] = wave_sum(t_gt);
+        term[8] = wave_sum(t_ac);
+        term[9] = wave_sum(t_acol);
+        term[10] = t_via;
+        term[11] = t_ydev;
+        term[12] = (mask & (1u << 12)) ? wave_sum(t_mono) : T(0);
+        term[13] = (mask & (1u << 13)) ? wave_sum(t_sched) : T(0);
+        term[14] = t_gn;
+        T jtot = T(0);
+#pragma unroll
+        for (int i = 0; i < kNTerms; ++i)
+            if (mask & (1u << i)) jtot = (i == 0) ? a.w[i] * term[i] : jtot + a.w[i] * term[i];
+        mc = wave_min(mc);
+        if (lane == 0) {
+            a.cost[cand] = jtot;
+            if (a.minc) a.minc[cand] = mc;
+            if (a.flags) a.flags[cand] = (uint8_t)((mc < T(0) ? 1u : 0u) | (mc >= a.req ? 2u : 0u));
+        }
+        if (a.terms && lane < kNTerms) {
+            T v = T(0);
+#pragma unroll
+            for (int i = 0; i < kNTerms; ++i) v = (lane == i) ? term[i] : v;
+            a.terms[cand * kNTerms + lane] = v;
+        }
+
+        if (GRAD) {
+            // (1) clearance chain: scatter d cost/d d_k * d d_k/d(P,yaw) to the sample it came from
+            wave_lds_sync();
+            const T DEG2RAD = T(0.017453292519943295);
+            for (int k = lane; k < Sp; k += 64) {
+                const T gd = GD[k];
+                const int arg = ARG[k];
+                if (gd != T(0) && arg >= 0) {
+                    const int s = a.idx_safe[k];
+                    const BoxRec<T> bx = boxes[arg];
+                    if (MODEL == 1) {
+                        Pose<T> ps;
+                        pose_setup(ps, P0[s], P1[s], P2[s], CC[k], SS[k], a.ax, a.ay);
+                        T g0, g1, g2, g3;
+                        pair_grad(ps, a.ax, a.ay, a.az, bx, g0, g1, g2, g3);
+                        G0[s] = gd * g0; G1[s] = gd * g1; G2[s] = gd * g2;
+                        GY[s] = gd * g3 * DEG2RAD;
+                    } else {
+                        T g0, g1, g2;
+                        point_grad(P0[s], P1[s], P2[s], bx, g0, g1, g2);
+                        G0[s] = gd * g0; G1[s] = gd * g1; G2[s] = gd * g2;
+                    }
+                }
+            }
+            // (2) curvature: T1 = A1 + G^T A2 (kept in D1*)
+            const bool curv = (mask & 2u) && S >= 3;
+            if (curv) {
+                for (int s = lane; s < S; s += 64) {
+                    // (G^T v)[s]
+                    T tx = T(0), ty = T(0), tz = T(0);
+                    const T h2 = T(2) * du;
+                    if (s == 0) { tx -= A2x[0] / du; ty -= A2y[0] / du; tz -= A2z[0] / du; }
+                    if (s == 1) { tx += A2x[0] / du; ty += A2y[0] / du; tz += A2z[0] / du; }
+                    if (s == S - 2) { tx -= A2x[S - 1] / du; ty -= A2y[S - 1] / du; tz -= A2z[S - 1] / du; }
+                    if (s == S - 1) { tx += A2x[S - 1] / du; ty += A2y[S - 1] / du; tz += A2z[S - 1] / du; }
+                    if (s - 1 >= 1 && s - 1 <= S - 2) { tx += A2x[s - 1] / h2; ty += A2y[s - 1] / h2; tz += A2z[s - 1] / h2; }
+                    if (s + 1 >= 1 && s + 1 <= S - 2) { tx -= A2x[s + 1] / h2; ty -= A2y[s + 1] / h2; tz -= A2z[s + 1] / h2; }
+                    D1x[s] = A1x[s] + tx; D1y[s] = A1y[s] + ty; D1z[s] = A1z[s] + tz;
+                }
+            }
+            wave_lds_sync();
+            // (3) gather every contribution to gP[s], gyaw[s]
+            for (int s = lane; s < S; s += 64) {
+                T gx = G0[s], gy = G1[s], gz = G2[s], gw = GY[s];
+                const T px = P0[s], py = P1[s], pz = P2[s], yw = YW[s];
+                if (mask & 1u) {
+                    if (s >= 1) {
+                        T ex = px - P0[s - 1], ey = py - P1[s - 1], ez = pz - P2[s - 1];
+                        T n = mp_sqrt(ex * ex + ey * ey + ez * ez);
+                        if (n > T(0)) { T k = a.w[0] / n; gx += k * ex; gy += k * ey; gz += k * ez; }
+                    }
+                    if (s + 1 < S) {
+                        T ex = P0[s + 1] - px, ey = P1[s + 1] - py, ez = P2[s + 1] - pz;
+                        T n = mp_sqrt(ex * ex + ey * ey + ez * ez);
+                        if (n > T(0)) { T k = a.w[0] / n; gx -= k * ex; gy -= k * ey; gz -= k * ez; }
+                    }
+                }
+                if (curv) {
+                    const T h2 = T(2) * du;
+                    if (s == 0) { gx -= D1x[0] / du; gy -= D1y[0] / du; gz -= D1z[0] / du; }
+                    if (s == 1) { gx += D1x[0] / du; gy += D1y[0] / du; gz += D1z[0] / du; }
+                    if (s == S - 2) { gx -= D1x[S - 1] / du; gy -= D1y[S - 1] / du; gz -= D1z[S - 1] / du; }
+                    if (s == S - 1) { gx += D1x[S - 1] / du; gy += D1y[S - 1] / du; gz += D1z[S - 1] / du; }
+                    if (s - 1 >= 1 && s - 1 <= S - 2) { gx += D1x[s - 1] / h2; gy += D1y[s - 1] / h2; gz += D1z[s - 1] / h2; }
+                    if (s + 1 >= 1 && s + 1 <= S - 2) { gx -= D1x[s + 1] / h2; gy -= D1y[s + 1] / h2; gz -= D1z[s + 1] / h2; }
+                }
+                if (s == S - 1) { gx += gnx; gy += gny; gz += gnz; }
+                if (s == gn_first) { gx -= gnx; gy -= gny; gz -= gnz; }
+                if ((mask & 4u) && S >= 3) {  // yaw smoothness: e_i = y_i - 2 y_{i+1} + y_{i+2}
+                    const T k2 = a.w[2] * T(2);
+                    if (s + 2 < S) gw += k2 * (yw - T(2) * YW[s + 1] + YW[s + 2]);
+                    if (s >= 1 && s + 1 < S) gw -= T(2) * k2 * (YW[s - 1] - T(2) * yw + YW[s + 1]);
+                    if (s >= 2) gw += k2 * (YW[s - 2] - T(2) * YW[s - 1] + yw);
+                }
+                if (mask & (1u << 12)) {
+                    const T sg = tk.yaw_inc ? T(-1) : T(1);
+                    if (s >= 1) {
+                        T dy = yw - YW[s - 1];
+                        gw += a.w[12] * T(2) * npmax0(tk.yaw_inc ? -dy : dy) * sg;
+                    }
+                    if (s + 1 < S) {
+                        T dy = YW[s + 1] - yw;
+                        gw -= a.w[12] * T(2) * npmax0(tk.yaw_inc ? -dy : dy) * sg;
+                    }
+                }
+                if (mask & (1u << 13)) {
+                    T target = y0 + (y1 - y0) * a.tsched[s];
+                    gw += a.w[13] * T(2) * (yw - target);
+                }
+                A1x[s] = gx; A1y[s] = gy; A1z[s] = gz; A2x[s] = gw;
+            }
+            wave_lds_sync();
+            // (4) x-gradient: M^T g, one wave reduction per optimised coordinate
+            T *gout = a.grad + cand * D;
+            for (int j = 0; j < nf; ++j) {
+                T sx = T(0), sy = T(0), sz = T(0);
+                for (int s = lane; s < S; s += 64) {
+                    T m = a.M[(size_t)s * C + ff + j];
+                    sx += m * A1x[s]; sy += m * A1y[s]; sz += m * A1z[s];
+                }
+                sx = wave_sum(sx); sy = wave_sum(sy); sz = wave_sum(sz);
+                if (mask & (1u << 10)) {
+                    sx += a.w[10] * T(2) * (W[4 * (ff + j) + 0] - tk.ctrl[ff + j][0]);
+                    sy += a.w[10] * T(2) * (W[4 * (ff + j) + 1] - tk.ctrl[ff + j][1]);
+                    sz += a.w[10] * T(2) * (W[4 * (ff + j) + 2] - tk.ctrl[ff + j][2]);
+                }
+                if (lane == 0) { gout[3 * j + 0] = sx; gout[3 * j + 1] = sy; gout[3 * j + 2] = sz; }
+            }
+            for (int j = 0; j < nyf; ++j) {
+                T sw = T(0);
+                for (int s = lane; s < S; s += 64) sw += a.My[(size_t)s * Cy + 1 + j] * A2x[s];
+                sw = wave_sum(sw);
+                if (mask & (1u << 11)) sw += a.w[11] * T(2) * (W[4 * (1 + j) + 3] - tk.yaw_ctrl[1 + j]);
+                if (lane == 0) gout[3 * nf + j] = sw;
+            }
+        }
+        wave_lds_sync();  // the next candidate reuses the slice
+    }
+}
+
+// ---- stand-alone batched distance queries ------------------------------------------------
+template <typename T>
+__global__ void __launch_bounds__(256) point_sdf_kernel(long long n, const T *__restrict__ pts,
+                                                         const BoxRec<T> *__restrict__ boxes, int nb, T radius,
+                                                         T *__restrict__ out)
+{
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        int arg;
+        out[i] = point_distance(pts[3 * i], pts[3 * i + 1], pts[3 * i + 2], boxes, nb, radius, arg);
+    }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) box_sdf_kernel(long long n, const T *__restrict__ pos, const T *__restrict__ yaw,
+                                                       const BoxRec<T> *__restrict__ boxes, int nb, T ax, T ay, T az,
+                                                       T *__restrict__ out)
+{
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        T c, s;
+        yaw_rot(yaw[i], c, s);
+        Pose<T> ps;
+        pose_setup(ps, pos[3 * i], pos[3 * i + 1], pos[3 * i + 2], c, s, ax, ay);
+        int arg;
+        out[i] = pose_distance(ps, ax, ay, az, boxes, nb, arg);
+    }
+}
+
+}  // namespace mp

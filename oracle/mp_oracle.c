@@ -73,8 +73,13 @@ typedef double real;
 static void orc_sincos(real h, real *sn, real *cs)
 {
     const real TWO_OVER_PI = RL(0.63661977236758134308);
-    const real PIO2_HI = RL(1.57079632679489655800e+00);
-    const real PIO2_LO = RL(6.12323399573676603587e-17);
+#ifdef ORC_F32
+    const real PIO2_HI = 1.57079637050628662109e+00f;
+    const real PIO2_LO = -4.37113882867379288655e-08f;
+#else
+    const real PIO2_HI = 1.57079632679489655800e+00;
+    const real PIO2_LO = 6.12323399573676603587e-17;
+#endif
     const real S1 = RL(-1.66666666666666324348e-01), S2 = RL(8.33333333332248946124e-03),
                S3 = RL(-1.98412698298579493134e-04), S4 = RL(2.75573137070700676789e-06),
                S5 = RL(-2.50507602534068634195e-08), S6 = RL(1.58969099521155010221e-10);
