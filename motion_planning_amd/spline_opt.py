@@ -1,0 +1,476 @@
+"""Planner / optimiser call surface of the reference (geom/spline_opt.py), backed by the
+MI355X kernels.
+
+``optimize_bspline_path`` (ref :391-746), ``optimize_bspline_with_vias`` (:749-849) and
+``optimize_bspline_two_vias`` (:852-884) keep the reference's signatures, defaults, ValueErrors,
+return tuples and ``info`` keys.  What changed is underneath: the objective closure is replaced
+by one native call per optimiser query (`mp_eval` through ``NativeEvaluator``) — one candidate
+for SciPy's Powell / Nelder-Mead, a whole population for the CEM — instead of S x B Python-level
+FCL calls per evaluation.
+
+The optimiser drivers stay on the host in "parity mode": SciPy's ``minimize`` and a CEM that
+draws its noise from ``np.random.default_rng(seed)`` exactly like the reference, so that a
+seeded solve visits the same candidates.
+"""
+from __future__ import annotations
+
+from typing import Callable, Dict, List, Optional, Tuple
+
+import numpy as np
+
+try:
+    from scipy.interpolate import make_interp_spline
+    from scipy.optimize import minimize
+except ImportError as e:  # same behaviour as the reference module (:4-8)
+    raise ImportError("Please install SciPy: pip install scipy") from e
+
+from . import _abi as abi
+from .problem import PathProblem, build_path_problem, build_vias_problem, default_via_initialization
+
+# ---------------------------------------------------------------------------------------------
+# small host-side helpers that are part of the reference module's public surface
+# ---------------------------------------------------------------------------------------------
+
+
+def build_cubic_bspline(points: np.ndarray) -> Callable[[np.ndarray], np.ndarray]:
+    """Interpolating cubic B-spline through N >= 4 waypoints, parameter u in [0, 1] (ref :11-22)."""
+    n = points.shape[0]
+    if n < 4:
+        raise ValueError("Cubic B-spline interpolation requires at least 4 waypoints.")
+    spl = make_interp_spline(np.linspace(0.0, 1.0, n), points, k=3, axis=0)
+    return lambda uq: spl(np.asarray(uq, dtype=float))
+
+
+def build_scalar_bspline(values: np.ndarray) -> Callable[[np.ndarray], np.ndarray]:
+    """Scalar interpolating spline of degree min(3, n - 1) (ref :25-34)."""
+    y = np.asarray(values, dtype=float).reshape(-1)
+    if y.size < 2:
+        raise ValueError("Scalar spline requires at least 2 control points.")
+    spl = make_interp_spline(np.linspace(0.0, 1.0, y.size), y, k=min(3, y.size - 1), axis=0)
+    return lambda uq: np.asarray(spl(np.asarray(uq, dtype=float)), dtype=float)
+
+
+def yaw_deg_to_quat(yaw_deg: float) -> Tuple[float, float, float, float]:
+    """[x, y, z, w] of a rotation by ``yaw_deg`` about +z (ref :37-40)."""
+    half = 0.5 * np.deg2rad(float(yaw_deg))
+    return (0.0, 0.0, float(np.sin(half)), float(np.cos(half)))
+
+
+def sample_curve(S: Callable, n: int = 101) -> Tuple[np.ndarray, np.ndarray]:
+    P = S(np.linspace(0.0, 1.0, n))
+    return P, np.diff(P, axis=0)
+
+
+def path_length(P: np.ndarray) -> float:
+    return float(np.sum(np.linalg.norm(np.diff(P, axis=0), axis=1)))
+
+
+def mean_turn_angle_deg(P: np.ndarray, eps: float = 1e-12) -> float:
+    """Mean angle between consecutive polyline segments, degrees (ref :82-97)."""
+    seg = np.diff(P, axis=0)
+    if seg.shape[0] < 2:
+        return 0.0
+    a, b = seg[:-1], seg[1:]
+    na, nb = np.linalg.norm(a, axis=1), np.linalg.norm(b, axis=1)
+    ok = (na > eps) & (nb > eps)
+    if not np.any(ok):
+        return 0.0
+    cosang = np.clip(np.sum(a[ok] * b[ok], axis=1) / (na[ok] * nb[ok]), -1.0, 1.0)
+    return float(np.degrees(np.mean(np.arccos(cosang))))
+
+
+_default_via_initialization = default_via_initialization
+
+# ---------------------------------------------------------------------------------------------
+# native evaluator
+# ---------------------------------------------------------------------------------------------
+
+
+class NativeEvaluator:
+    """objective_batch of the reference (:301-302) as one kernel launch per call."""
+
+    def __init__(self, problem: PathProblem, device: int = 0, dtype=np.float64):
+        from . import _native
+
+        self.problem = problem
+        self.ctx = _native.Context(device, dtype)
+        self.ctx.set_problem(problem)
+        self.n_calls = 0
+        self.n_evals = 0
+
+    def __call__(self, X: np.ndarray, want_terms: bool = False, want_grad: bool = False, want_dist: bool = False):
+        X = np.asarray(X, dtype=float)
+        if X.ndim == 1:
+            X = X[None, :]
+        self.n_calls += 1
+        self.n_evals += X.shape[0]
+        out = self.ctx.eval(X, want_terms=want_terms, want_grad=want_grad, want_dist=want_dist)
+        return {k: (None if v is None else np.asarray(v, dtype=float) if k != "flags" else v) for k, v in out.items()}
+
+    def clearance_profile(self, P: np.ndarray, yaw_deg: Optional[np.ndarray]) -> np.ndarray:
+        """_path_distances over arbitrary samples (ref :148-186) with the problem's scene."""
+        p = self.problem
+        if p.boxes.shape[0] == 0:
+            return np.full(P.shape[0], np.inf)
+        if p.model == abi.MP_MODEL_BOX:
+            yaw = np.zeros(P.shape[0]) if yaw_deg is None else yaw_deg
+            return np.asarray(self.ctx.box_sdf(2.0 * p.half_extents, P, yaw), dtype=float)
+        return np.asarray(self.ctx.point_sdf(P, p.point_radius), dtype=float)
+
+    def close(self) -> None:
+        self.ctx.close()
+
+
+EvaluatorFactory = Callable[[PathProblem], Callable]
+
+# ---------------------------------------------------------------------------------------------
+# optimiser drivers (host, parity mode)
+# ---------------------------------------------------------------------------------------------
+
+
+def _cem_optimize(objective, x0, sigma0, population_size: int = 96, elite_frac: float = 0.2, max_iter: int = 120,
+                  tol: float = 1e-3, alpha: float = 0.7, min_sigma: float = 1e-3, seed: Optional[int] = None):
+    """Cross-entropy method with the reference's update and stopping rule (ref :222-277).
+
+    ``objective`` maps a (population, D) array to (population,) costs: one native launch."""
+    rng = np.random.default_rng(seed)
+    mean = x0.astype(float).copy()
+    spread = np.maximum(np.asarray(sigma0, dtype=float), min_sigma)
+    dim = mean.size
+    n_elite = max(2, int(np.ceil(population_size * elite_frac)))
+    incumbent, incumbent_val, previous_val = mean.copy(), float("inf"), float("inf")
+    generations = 0
+    while generations < max_iter:
+        generations += 1
+        noise = rng.normal(size=(population_size, dim))
+        population = mean[None, :] + noise * spread[None, :]
+        values = objective(population)
+        lead = int(np.argmin(values))
+        if values[lead] < incumbent_val:
+            incumbent_val = float(values[lead])
+            incumbent = population[lead].copy()
+        chosen = population[np.argpartition(values, n_elite - 1)[:n_elite]]
+        mean = alpha * mean + (1.0 - alpha) * np.mean(chosen, axis=0)
+        spread = np.maximum(alpha * spread + (1.0 - alpha) * (np.std(chosen, axis=0) + min_sigma), min_sigma)
+        if np.abs(previous_val - incumbent_val) < tol and float(np.max(spread)) < 0.03:
+            break
+        previous_val = incumbent_val
+    return {"x": incumbent, "fun": incumbent_val, "nit": generations, "success": True, "message": "CEM finished"}
+
+
+_CEM_DEFAULTS = dict(population_size=64, elite_frac=0.2, max_iter=90, tol=1e-3, alpha=0.7, min_sigma=1e-3, seed=None)
+_HYBRID_CEM_DEFAULTS = dict(population_size=48, elite_frac=0.2, max_iter=60, tol=1e-3, alpha=0.7, min_sigma=1e-3, seed=None)
+_HYBRID_POWELL_DEFAULTS = dict(maxiter=80, xtol=1e-3, ftol=1e-3)
+
+
+def _solve_optimizer(objective_single, x0, sigma0, method: str, options: Optional[Dict] = None,
+                     objective_batch: Optional[Callable] = None) -> Dict:
+    """Method dispatch and option merging of the reference (ref :280-388).
+
+    ``objective_single(x)`` returns a tuple whose element 0 is the cost; ``objective_batch(X)``
+    (optional) returns the cost vector of a population in one call."""
+    if objective_batch is None:
+        def objective_batch(X):
+            return np.array([objective_single(x)[0] for x in X], dtype=float)
+
+    def scalar(x):
+        return objective_single(x)[0]
+
+    name = method.upper()
+    if name == "CEM":
+        cem = dict(_CEM_DEFAULTS)
+        if options:
+            cem.update(options)
+        res = _cem_optimize(objective_batch, x0=x0, sigma0=sigma0, **cem)
+        return {"x": res["x"], "success": bool(res["success"]), "message": str(res["message"]), "nit": int(res["nit"]),
+                "fun": float(res["fun"])}
+
+    if name in {"CEM-POWELL", "HYBRID"}:
+        cem, powell = dict(_HYBRID_CEM_DEFAULTS), dict(_HYBRID_POWELL_DEFAULTS)
+        if options:
+            if isinstance(options.get("cem"), dict):
+                cem.update(options["cem"])
+            if isinstance(options.get("powell"), dict):
+                powell.update(options["powell"])
+            for key, val in options.items():
+                if key in cem:
+                    cem[key] = val
+                if key in powell:
+                    powell[key] = val
+        stage1 = _cem_optimize(objective_batch, x0=x0, sigma0=sigma0, **cem)
+        stage2 = minimize(scalar, stage1["x"], method="Powell", options=powell)
+        if float(stage2.fun) <= float(stage1["fun"]):
+            return {"x": stage2.x, "success": bool(stage2.success), "message": f"Hybrid CEM+Powell: {stage2.message}",
+                    "nit": int(getattr(stage2, "nit", 0)) + int(stage1["nit"]), "fun": float(stage2.fun)}
+        return {"x": stage1["x"], "success": bool(stage1["success"]), "message": "Hybrid CEM+Powell: kept CEM result",
+                "nit": int(stage1["nit"]), "fun": float(stage1["fun"])}
+
+    if name in {"NELDER", "NEAD-MELDER", "NEAD_MELDER"}:
+        method, name = "Nelder-Mead", "NELDER-MEAD"
+    if name == "POWELL":
+        scipy_options = {"maxiter": 220, "xtol": 1e-3, "ftol": 1e-3}
+    elif name == "NELDER-MEAD":
+        scipy_options = {"maxiter": 300, "xatol": 1e-3, "fatol": 1e-3}
+    else:
+        scipy_options = {"maxiter": 250, "xatol": 1e-3, "fatol": 1e-3}
+    if options:
+        nested = options.get(method.lower().replace("-", "_"))
+        scipy_options.update(nested if isinstance(nested, dict) else options)
+    res = minimize(scalar, x0, method=method, options=scipy_options)
+    return {"x": res.x, "success": bool(res.success), "message": str(res.message), "nit": int(getattr(res, "nit", 0)),
+            "fun": float(res.fun)}
+
+
+def _make_evaluator(problem: PathProblem, evaluator_factory: Optional[EvaluatorFactory], device: int, dtype):
+    if evaluator_factory is not None:
+        return evaluator_factory(problem)
+    return NativeEvaluator(problem, device=device, dtype=dtype)   # raises without the HIP library / a GPU
+
+
+# ---------------------------------------------------------------------------------------------
+# planner entry points
+# ---------------------------------------------------------------------------------------------
+
+
+def optimize_bspline_path(
+    scene,
+    start: np.ndarray,
+    goal: np.ndarray,
+    n_vias: int = 3,
+    tool_half_extents: Tuple[float, float, float] = (0.0, 0.0, 0.0),
+    moving_block_size: Optional[Tuple[float, float, float]] = None,
+    moving_block_quat: Tuple[float, float, float, float] = (0.0, 0.0, 0.0, 1.0),
+    collision_ignore_ids: Optional[List[str]] = None,
+    safety_margin: float = 0.01,
+    n_samples_curve: int = 121,
+    collision_check_subsample: int = 1,
+    start_yaw_deg: float = 0.0,
+    goal_yaw_deg: float = 0.0,
+    n_yaw_vias: int = 0,
+    combined_4d: bool = True,
+    w_len: float = 1.0,
+    w_curv: float = 0.1,
+    w_yaw_smooth: float = 0.0,
+    w_safe: float = 50.0,
+    preferred_safety_margin: Optional[float] = None,
+    relax_preferred_final_fraction: float = 0.0,
+    w_safe_preferred: float = 0.0,
+    w_approach_rebound: float = 0.0,
+    w_goal_clearance: float = 0.0,
+    goal_clearance_target: Optional[float] = None,
+    w_goal_clearance_target: float = 0.0,
+    approach_only_clearance: Optional[float] = None,
+    contact_window_fraction: float = 0.1,
+    w_approach_clearance: float = 0.0,
+    w_approach_collision: float = 0.0,
+    approach_fraction: float = 0.2,
+    w_via_dev: float = 0.0,
+    w_yaw_dev: float = 0.0,
+    w_yaw_monotonic: float = 0.0,
+    yaw_goal_reach_u: float = 1.0,
+    w_yaw_schedule: float = 0.0,
+    goal_approach_normals: Optional[np.ndarray] = None,
+    goal_approach_window_fraction: float = 0.1,
+    w_goal_approach_normal: float = 0.0,
+    init_offset_scale: float = 1.0,
+    method: str = "Powell",
+    options: Optional[Dict] = None,
+    *,
+    device: int = 0,
+    dtype=np.float64,
+    evaluator_factory: Optional[EvaluatorFactory] = None,
+) -> Tuple[Callable[[np.ndarray], np.ndarray], np.ndarray, Dict]:
+    """Optimise all vias (and yaw controls) of the cubic B-spline through [start, vias..., goal].
+
+    Same contract as the reference's function of this name.  ``moving_block_quat`` is accepted and
+    unused, as in the reference (per-sample yaw quaternions always take precedence, :538-545).
+    Keyword-only extras: ``device`` (GPU index), ``dtype`` (float64 / float32 kernels) and
+    ``evaluator_factory`` (dependency injection for tests; the default is the HIP library)."""
+    from . import _native
+
+    problem = build_path_problem(
+        scene, start, goal, _native.build_basis, n_vias=n_vias, tool_half_extents=tool_half_extents,
+        moving_block_size=moving_block_size, collision_ignore_ids=collision_ignore_ids, safety_margin=safety_margin,
+        n_samples_curve=n_samples_curve, collision_check_subsample=collision_check_subsample,
+        start_yaw_deg=start_yaw_deg, goal_yaw_deg=goal_yaw_deg, n_yaw_vias=n_yaw_vias, combined_4d=combined_4d,
+        w_len=w_len, w_curv=w_curv, w_yaw_smooth=w_yaw_smooth, w_safe=w_safe,
+        preferred_safety_margin=preferred_safety_margin, relax_preferred_final_fraction=relax_preferred_final_fraction,
+        w_safe_preferred=w_safe_preferred, w_approach_rebound=w_approach_rebound, w_goal_clearance=w_goal_clearance,
+        goal_clearance_target=goal_clearance_target, w_goal_clearance_target=w_goal_clearance_target,
+        approach_only_clearance=approach_only_clearance, contact_window_fraction=contact_window_fraction,
+        w_approach_clearance=w_approach_clearance, w_approach_collision=w_approach_collision,
+        approach_fraction=approach_fraction, w_via_dev=w_via_dev, w_yaw_dev=w_yaw_dev, w_yaw_monotonic=w_yaw_monotonic,
+        yaw_goal_reach_u=yaw_goal_reach_u, w_yaw_schedule=w_yaw_schedule, goal_approach_normals=goal_approach_normals,
+        goal_approach_window_fraction=goal_approach_window_fraction, w_goal_approach_normal=w_goal_approach_normal,
+        init_offset_scale=init_offset_scale,
+    )
+    start = np.asarray(start, float).reshape(3)
+    goal = np.asarray(goal, float).reshape(3)
+    evaluate = _make_evaluator(problem, evaluator_factory, device, dtype)
+    n_pos = 3 * problem.n_free
+
+    def objective_single(x):
+        return (float(evaluate(np.asarray(x, dtype=float)[None, :])["cost"][0]),)
+
+    def objective_batch(X):
+        return np.asarray(evaluate(X)["cost"], dtype=float)
+
+    opt = _solve_optimizer(objective_single, x0=problem.x0, sigma0=problem.sigma0, method=method, options=options,
+                           objective_batch=objective_batch)
+    x_opt = np.asarray(opt["x"], dtype=float)
+    vias_opt = x_opt[:n_pos].reshape(problem.n_free, 3)
+    if problem.n_yaw_free > 0:
+        yaw_ctrl_opt = np.hstack([[float(start_yaw_deg)], x_opt[n_pos:], [float(goal_yaw_deg)]])
+    else:
+        yaw_ctrl_opt = np.array([float(start_yaw_deg), float(goal_yaw_deg)], dtype=float)
+
+    # callables over arbitrary u (SciPy on the host, as the reference does after the solve, :648-675)
+    us = np.linspace(0.0, 1.0, problem.n_samples)
+    if combined_4d:
+        S4 = build_cubic_bspline(np.hstack([np.vstack([start, vias_opt, goal]), yaw_ctrl_opt.reshape(-1, 1)]))
+
+        def S_opt(uq):
+            q = np.asarray(S4(uq), dtype=float)
+            return q[:3].reshape(1, 3) if q.ndim == 1 else q[:, :3]
+
+        def S_yaw_opt(uq):
+            q = np.asarray(S4(uq), dtype=float)
+            return np.array([q[3]], dtype=float) if q.ndim == 1 else q[:, 3]
+
+        Q = S4(us)
+        P_opt, yaw_samples_opt = Q[:, :3], Q[:, 3]
+    else:
+        S_opt = build_cubic_bspline(np.vstack([start, vias_opt, goal]))
+        S_yaw_opt = build_scalar_bspline(yaw_ctrl_opt)
+        P_opt, yaw_samples_opt = S_opt(us), S_yaw_opt(us)
+
+    final = evaluate(x_opt[None, :], want_terms=True)
+    terms = np.asarray(final["terms"], dtype=float)[0]
+    d_opt = evaluate.clearance_profile(np.ascontiguousarray(P_opt), np.ascontiguousarray(yaw_samples_opt))
+
+    info = {"success": opt["success"], "message": opt["message"], "fun": opt["fun"]}
+    for name, value in zip(abi.TERM_NAMES, terms):
+        info[name] = float(value)
+    info.update({
+        "min_clearance": float(np.min(d_opt)),
+        "mean_clearance": float(np.mean(d_opt)),
+        "turn_angle_mean_deg": mean_turn_angle_deg(P_opt),
+        "yaw_start_deg": float(start_yaw_deg),
+        "yaw_goal_deg": float(goal_yaw_deg),
+        "yaw_ctrl_deg": yaw_ctrl_opt.copy(),
+        "yaw_samples_deg": np.array(yaw_samples_opt, dtype=float, copy=True),
+        "yaw_fn": S_yaw_opt,
+        "combined_4d": bool(combined_4d),
+        "solver_method": method,
+        "required_clearance": problem.required_clearance,
+        "preferred_clearance": problem.preferred_clearance,
+        "goal_clearance_target": goal_clearance_target,
+        "approach_only_clearance": approach_only_clearance,
+        "contact_window_fraction": float(contact_window_fraction),
+        "goal_approach_window_fraction": float(goal_approach_window_fraction),
+        "goal_approach_normals": None if goal_approach_normals is None else np.asarray(goal_approach_normals, dtype=float).copy(),
+        "yaw_goal_reach_u": float(yaw_goal_reach_u),
+        "collision_model": "box" if problem.model == abi.MP_MODEL_BOX else "point",
+        "nit": opt["nit"],
+    })
+    _close(evaluate)
+    return S_opt, vias_opt, info
+
+
+def _close(evaluate) -> None:
+    fn = getattr(evaluate, "close", None)
+    if callable(fn):
+        fn()
+
+
+def optimize_bspline_with_vias(
+    scene,
+    start: np.ndarray,
+    via: np.ndarray,
+    goal: np.ndarray,
+    n_additional_vias: int = 2,
+    tool_half_extents: Tuple[float, float, float] = (0.0, 0.0, 0.0),
+    safety_margin: float = 0.01,
+    n_samples_curve: int = 121,
+    collision_check_subsample: int = 1,
+    w_len: float = 1.0,
+    w_curv: float = 0.1,
+    w_safe: float = 50.0,
+    init_offset_scale: float = 1.0,
+    method: str = "CEM",
+    options: Optional[Dict] = None,
+    *,
+    device: int = 0,
+    dtype=np.float64,
+    evaluator_factory: Optional[EvaluatorFactory] = None,
+) -> Tuple[Callable[[np.ndarray], np.ndarray], np.ndarray, Dict]:
+    """Optimise N additional vias of the spline through [start, via, vias..., goal] for length,
+    curvature and the safety margin (3-term objective; same contract as the reference, :749-849)."""
+    from . import _native
+
+    problem = build_vias_problem(
+        scene, start, via, goal, _native.build_basis, n_additional_vias=n_additional_vias,
+        tool_half_extents=tool_half_extents, safety_margin=safety_margin, n_samples_curve=n_samples_curve,
+        collision_check_subsample=collision_check_subsample, w_len=w_len, w_curv=w_curv, w_safe=w_safe,
+        init_offset_scale=init_offset_scale,
+    )
+    start = np.asarray(start, float).reshape(3)
+    via = np.asarray(via, float).reshape(3)
+    goal = np.asarray(goal, float).reshape(3)
+    evaluate = _make_evaluator(problem, evaluator_factory, device, dtype)
+
+    def objective_single(x):
+        return (float(evaluate(np.asarray(x, dtype=float)[None, :])["cost"][0]),)
+
+    def objective_batch(X):
+        return np.asarray(evaluate(X)["cost"], dtype=float)
+
+    opt = _solve_optimizer(objective_single, x0=problem.x0, sigma0=problem.sigma0, method=method, options=options,
+                           objective_batch=objective_batch)
+    x_opt = np.asarray(opt["x"], dtype=float)
+    vias_opt = x_opt.reshape(n_additional_vias, 3)
+    S_opt = build_cubic_bspline(np.vstack([start, via, vias_opt, goal]))
+    P_opt, _ = sample_curve(S_opt, n=n_samples_curve)
+    terms = np.asarray(evaluate(x_opt[None, :], want_terms=True)["terms"], dtype=float)[0]
+    d_opt = evaluate.clearance_profile(np.ascontiguousarray(P_opt), None)
+    info = {
+        "success": opt["success"],
+        "message": opt["message"],
+        "fun": opt["fun"],
+        "length": float(terms[abi.T_LEN]),
+        "curvature_cost": float(terms[abi.T_CURV]),
+        "safety_cost": float(terms[abi.T_SAFE]),
+        "min_clearance": float(np.min(d_opt)),
+        "mean_clearance": float(np.mean(d_opt)),
+        "turn_angle_mean_deg": mean_turn_angle_deg(P_opt),
+        "required_clearance": problem.required_clearance,
+        "collision_model": "box" if problem.model == abi.MP_MODEL_BOX else "point",
+        "nit": opt["nit"],
+    }
+    _close(evaluate)
+    return S_opt, vias_opt, info
+
+
+def optimize_bspline_two_vias(
+    scene,
+    start: np.ndarray,
+    via: np.ndarray,
+    goal: np.ndarray,
+    tool_half_extents: Tuple[float, float, float] = (0.0, 0.0, 0.0),
+    safety_margin: float = 0.01,
+    n_samples_curve: int = 121,
+    w_len: float = 1.0,
+    w_curv: float = 0.1,
+    w_safe: float = 50.0,
+    init_offset_scale: float = 0.3,
+    method: str = "Nelder-Mead",
+    options: Dict = None,
+    **native_kwargs,
+) -> Tuple[Callable[[np.ndarray], np.ndarray], np.ndarray, np.ndarray, Dict]:
+    """Two-additional-vias wrapper kept for callers of the older API (ref :852-884)."""
+    S, vias, info = optimize_bspline_with_vias(
+        scene=scene, start=start, via=via, goal=goal, n_additional_vias=2, tool_half_extents=tool_half_extents,
+        safety_margin=safety_margin, n_samples_curve=n_samples_curve, w_len=w_len, w_curv=w_curv, w_safe=w_safe,
+        init_offset_scale=init_offset_scale, method=method, options=options, **native_kwargs,
+    )
+    return S, vias[0], vias[1], info

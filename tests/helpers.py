@@ -1,0 +1,57 @@
+"""Shared helpers of the test-suite: golden fixtures -> PathProblem."""
+from __future__ import annotations
+
+import json
+from pathlib import Path
+
+import numpy as np
+
+from motion_planning_amd import _native
+from motion_planning_amd.blocks import Block
+from motion_planning_amd.problem import build_path_problem, build_vias_problem
+from motion_planning_amd.synthetic import BoxList
+
+GOLDEN = Path(__file__).resolve().parent / "golden"
+
+
+def load_cases():
+    return json.loads((GOLDEN / "g3_cases.json").read_text())
+
+
+def load_g3():
+    return np.load(GOLDEN / "g3_objective.npz")
+
+
+def load_scenarios():
+    return json.loads((GOLDEN / "scenarios.json").read_text())["scenarios"]
+
+
+def blocks_from(entries):
+    return [Block(tuple(b["size"]), tuple(b["position"]), object_id=b["id"]) for b in entries]
+
+
+def _kw(kwargs):
+    kw = dict(kwargs)
+    if kw.get("goal_approach_normals") is not None:
+        kw["goal_approach_normals"] = np.asarray(kw["goal_approach_normals"], dtype=float)
+    for k in ("moving_block_size", "tool_half_extents"):
+        if kw.get(k) is not None:
+            kw[k] = tuple(kw[k])
+    return kw
+
+
+def problem_for_case(case, basis_fn=None):
+    basis_fn = basis_fn or _native.build_basis
+    scene = BoxList(blocks_from(case["blocks"]))
+    kw = _kw(case["kwargs"])
+    if case["fn"] == "optimize_bspline_path":
+        return build_path_problem(scene, case["args"][0], case["args"][1], basis_fn, **kw)
+    return build_vias_problem(scene, case["args"][0], case["args"][1], case["args"][2], basis_fn, **kw)
+
+
+def rel_err(got, ref, floor=1e-12):
+    got = np.asarray(got, dtype=float)
+    ref = np.asarray(ref, dtype=float)
+    with np.errstate(invalid="ignore"):
+        e = np.abs(got - ref) / np.maximum(np.abs(ref), floor)
+    return np.where(np.isfinite(e), e, 0.0)

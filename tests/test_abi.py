@@ -1,0 +1,85 @@
+"""The C-ABI library: loads without a GPU, exports every symbol include/mp_api.h declares,
+and its ctypes mirror has the C struct layout.  No compute calls here."""
+import ctypes as C
+import re
+import subprocess
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+from motion_planning_amd import _abi as abi
+from motion_planning_amd import _native
+
+ROOT = Path(__file__).resolve().parents[1]
+HEADER = (ROOT / "include" / "mp_api.h").read_text()
+
+
+def declared_symbols():
+    return sorted(set(re.findall(r"^(?:int|const char \*)\s*\*?(mp_[a-z_0-9]+)\(", HEADER, flags=re.M)))
+
+
+def test_library_exports_every_declared_symbol():
+    lib = _native.load()
+    syms = declared_symbols()
+    assert len(syms) >= 16, syms
+    for s in syms:
+        assert hasattr(lib, s), f"{s} is declared in mp_api.h but not exported"
+    assert lib.mp_api_version() == abi.MP_API_VERSION
+
+
+def test_compute_entry_points_cite_the_reference():
+    # the comment block in front of each hot-path entry point names the reference file:line it replaces
+    for sym in ("mp_set_scene", "mp_set_problem", "mp_build_basis", "mp_eval", "mp_point_sdf", "mp_box_sdf"):
+        pos = HEADER.index("int " + sym + "(")
+        assert re.search(r"geom/(spline_opt|scene|blocks)\.py:\d+", HEADER[max(0, pos - 2500):pos]), sym
+
+
+def test_struct_layout_matches_the_header(tmp_path):
+    src = tmp_path / "sz.c"
+    src.write_text(
+        '#include <stdio.h>\n#include <stddef.h>\n#include "mp_api.h"\n'
+        'int main(void){printf("%zu %zu %zu %zu %zu %zu %zu\\n", sizeof(mp_config), sizeof(mp_task),'
+        ' offsetof(mp_config, weights), offsetof(mp_config, idx_safe), offsetof(mp_config, t_sched),'
+        ' offsetof(mp_task, goal_normal), offsetof(mp_task, box_count));return 0;}\n'
+    )
+    exe = tmp_path / "sz"
+    subprocess.run(["gcc", "-I", str(ROOT / "include"), str(src), "-o", str(exe)], check=True)
+    got = [int(v) for v in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split()]
+    want = [C.sizeof(abi.MpConfig), C.sizeof(abi.MpTask), abi.MpConfig.weights.offset, abi.MpConfig.idx_safe.offset,
+            abi.MpConfig.t_sched.offset, abi.MpTask.goal_normal.offset, abi.MpTask.box_count.offset]
+    assert got == want
+
+
+def test_build_basis_rejects_bad_arguments():
+    lib = _native.load()
+    buf = np.zeros(64 * 16)
+    p = buf.ctypes.data_as(C.c_void_p)
+    assert lib.mp_build_basis(4, 3, 64, p) == abi.MP_OK
+    assert lib.mp_build_basis(3, 3, 64, p) == abi.MP_E_ARG      # cubic needs >= 4 points
+    assert lib.mp_build_basis(4, 4, 64, p) == abi.MP_E_ARG
+    assert lib.mp_build_basis(4, 3, 1, p) == abi.MP_E_ARG
+    assert lib.mp_build_basis(17, 3, 64, p) == abi.MP_E_ARG
+    assert lib.mp_build_basis(4, 3, 64, None) == abi.MP_E_ARG
+
+
+def test_no_gpu_means_a_loud_failure_not_a_fallback():
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    with pytest.raises(_native.NativeError, match="no HIP device|no CPU fallback"):
+        _native.Context(0)
+    from motion_planning_amd import spline_opt as so
+    from motion_planning_amd.synthetic import BoxList
+
+    with pytest.raises(_native.NativeError):
+        so.optimize_bspline_path(BoxList([]), (0, 0, 0), (1, 1, 1), n_vias=2)
+
+
+def test_product_never_imports_the_oracle():
+    for path in (ROOT / "motion_planning_amd").rglob("*"):
+        if path.suffix in (".py", ".hip", ".hpp", ".cpp", ".h"):
+            text = path.read_text()
+            for needle in ("import oracle", "from oracle", "mp_oracle", "libmp_oracle", "orc_eval"):
+                assert needle not in text, (path, needle)

@@ -1,0 +1,109 @@
+"""Distance semantics of the oracle (the definition the HIP kernels are held to).
+
+The reference delegates distances to python-fcl, which is absent here and un-pinned there, so
+these values are "parity unpinned" against the reference (see oracle/mp_oracle.c header).  They
+are pinned instead against hand-derivable cases and an independent numerical method
+(bounded least squares for separated boxes, a 15-axis SAT for penetration depth)."""
+import numpy as np
+import pytest
+from scipy.optimize import lsq_linear
+
+TABLE = np.array([[0.0, 0.0, 0.0, 1.0, 0.5, 0.25]])  # centre, half extents
+
+
+def test_hand_cases_box(oracle_lib):
+    size = (0.4, 0.2, 0.2)  # half 0.2, 0.1, 0.1
+    q = lambda pos, yaw: float(oracle_lib.box_sdf(TABLE, size, np.array([pos]), np.array([yaw]))[0])
+    assert q((2.0, 0.0, 0.0), 0.0) == pytest.approx(2.0 - 1.0 - 0.2, abs=1e-15)          # face-face in x
+    assert q((0.0, 0.0, 1.0), 33.0) == pytest.approx(1.0 - 0.25 - 0.1, abs=1e-15)        # above, any yaw
+    assert q((2.0, 0.0, 0.0), 90.0) == pytest.approx(2.0 - 1.0 - 0.1, abs=1e-15)         # rotated 90: short side faces
+    # vertex-vertex in xy, same z: corner (1,0.5) to corner of the mover at (1.5-0.2, 1.0-0.1)
+    assert q((1.5, 1.0, 0.0), 0.0) == pytest.approx(np.hypot(0.3, 0.4), abs=1e-15)
+    # edge-edge across z as well
+    assert q((1.5, 1.0, 0.75), 0.0) == pytest.approx(np.sqrt(0.3**2 + 0.4**2 + 0.4**2), abs=1e-15)
+    # 45 deg: the mover's corner points at the face
+    r = np.hypot(0.2, 0.1) * np.cos(np.arctan2(0.1, 0.2) - np.pi / 4)
+    assert q((2.0, 0.0, 0.0), 45.0) == pytest.approx(1.0 - r, abs=1e-14)
+    # touching is 0 and not a collision; overlap is minus the smallest overlap
+    assert q((1.2, 0.0, 0.0), 0.0) == 0.0
+    assert q((1.1, 0.0, 0.0), 0.0) == pytest.approx(-0.1, abs=1e-15)
+    assert q((0.0, 0.0, 0.0), 10.0) == pytest.approx(-0.35, abs=1e-15)                    # contained: z overlap is smallest
+    assert oracle_lib.box_sdf(np.zeros((0, 6)), size, np.zeros((1, 3)), np.zeros(1))[0] == np.inf
+
+
+def test_hand_cases_point(oracle_lib):
+    q = lambda p: float(oracle_lib.point_sdf(TABLE, np.array([p]), 1e-6)[0])
+    assert q((2.0, 0.0, 0.0)) == pytest.approx(1.0 - 1e-6, abs=1e-15)
+    assert q((2.0, 1.5, 0.0)) == pytest.approx(np.hypot(1.0, 1.0) - 1e-6, abs=1e-15)
+    assert q((0.0, 0.0, 0.0)) == pytest.approx(-0.25, abs=1e-15)
+    assert q((0.9, 0.0, 0.0)) == pytest.approx(-0.1, abs=1e-15)
+    assert q((1.0, 0.5, 0.25)) == 0.0                          # on the closed surface counts as inside
+    assert oracle_lib.point_sdf(np.zeros((0, 6)), np.zeros((1, 3)))[0] == np.inf
+
+
+def _corners(center, half, yaw_deg):
+    c, s = np.cos(np.radians(yaw_deg)), np.sin(np.radians(yaw_deg))
+    R = np.array([[c, -s, 0], [s, c, 0], [0, 0, 1.0]])
+    return R, np.asarray(center, float), np.asarray(half, float)
+
+
+def _independent_distance(pa, ha, yaw, cb, hb):
+    """min || (pa + Ra u) - (cb + v) ||, |u|<=ha, |v|<=hb as a bounded linear least squares."""
+    R, pa, ha = _corners(pa, ha, yaw)
+    A = np.hstack([R, -np.eye(3)])
+    b = np.asarray(cb, float) - pa
+    res = lsq_linear(A, b, bounds=(np.concatenate([-ha, -hb]), np.concatenate([ha, hb])), tol=1e-14, max_iter=500)
+    return float(np.linalg.norm(A @ res.x - b))
+
+
+def _sat_depth(pa, ha, yaw, cb, hb):
+    """max over the 15 SAT axes of the signed separation (negative = overlap depth)."""
+    R, pa, ha = _corners(pa, ha, yaw)
+    axes = [R[:, i] for i in range(3)] + [np.eye(3)[i] for i in range(3)]
+    axes += [np.cross(R[:, i], np.eye(3)[j]) for i in range(3) for j in range(3)]
+    d = pa - np.asarray(cb, float)
+    best = -np.inf
+    for ax in axes:
+        n = np.linalg.norm(ax)
+        if n < 1e-9:
+            continue
+        ax = ax / n
+        ra = np.sum(np.abs(R.T @ ax) * ha)
+        rb = np.sum(np.abs(ax) * hb)
+        best = max(best, abs(d @ ax) - ra - rb)
+    return best
+
+
+def test_box_distance_against_independent_solver(oracle_lib):
+    rng = np.random.default_rng(5)
+    n_sep = n_pen = 0
+    for _ in range(400):
+        hb = rng.uniform(0.05, 0.6, 3)
+        cb = rng.uniform(-0.5, 0.5, 3)
+        ha = rng.uniform(0.05, 0.5, 3)
+        pa = cb + rng.uniform(-1.5, 1.5, 3)
+        yaw = rng.choice([0.0, 90.0, rng.uniform(-180, 180)])
+        box = np.concatenate([cb, hb])[None, :]
+        got = float(oracle_lib.box_sdf(box, 2 * ha, pa[None, :], np.array([yaw]))[0])
+        depth = _sat_depth(pa, ha, yaw, cb, hb)
+        if depth > 1e-6:
+            ref = _independent_distance(pa, ha, yaw, cb, hb)
+            assert got == pytest.approx(ref, abs=2e-7), (pa, ha, yaw, cb, hb)
+            n_sep += 1
+        elif depth < -1e-6:
+            assert got == pytest.approx(depth, abs=1e-12)
+            n_pen += 1
+    assert n_sep > 100 and n_pen > 20
+
+
+def test_scene_value_is_min_over_boxes_and_ignores_nothing(oracle_lib):
+    rng = np.random.default_rng(6)
+    boxes = np.hstack([rng.uniform(-1, 1, (7, 3)), rng.uniform(0.05, 0.3, (7, 3))])
+    pos = rng.uniform(-2, 2, (50, 3))
+    yaw = rng.uniform(-90, 90, 50)
+    full = oracle_lib.box_sdf(boxes, (0.3, 0.2, 0.1), pos, yaw)
+    each = np.stack([oracle_lib.box_sdf(boxes[i:i + 1], (0.3, 0.2, 0.1), pos, yaw) for i in range(7)])
+    np.testing.assert_array_equal(full, each.min(axis=0))
+    pf = oracle_lib.point_sdf(boxes, pos)
+    pe = np.stack([oracle_lib.point_sdf(boxes[i:i + 1], pos) for i in range(7)])
+    np.testing.assert_array_equal(pf, pe.min(axis=0))
