@@ -1,0 +1,218 @@
+#!/usr/bin/env python3
+"""Headline benchmark: spline-candidate cost+gradient evaluations per second.
+
+Workload (BASELINE.json configs[2], the configuration the metric is quoted on — "64-sample,
+50-box scene"): per GPU 65,536 multi-start candidates x 64 samples x 50 axis-aligned boxes,
+fp64, full 15-term box-model objective + analytic gradient + min clearance + flags.  A "step"
+is one pass of the hot path over that batch (one mp_eval launch on HBM-resident inputs).
+Weak scaling: every rank owns its own 65,536 candidates (sharded by index), no data-path
+collective; the per-candidate (cost, min clearance, flags) of each step are all-gathered over
+RCCL asynchronously, overlapped with the next step.
+
+  python bench.py --gpus 1 --steps 20 --warmup 3
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+         --master-port P bench.py --gpus N --steps K --warmup W
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+
+N_CAND = 65536
+N_SAMPLES = 64
+N_BOXES = 50
+FP64_VALU_PEAK_TFLOPS = 78.6   # AMD MI355X datasheet, FP64 vector
+FP32_VALU_PEAK_TFLOPS = 157.3
+HBM_PEAK_GBPS = 8000.0
+
+
+def algorithmic_flops(S, Sp, B, C):
+    """F = S'*B*f_pair + S*f_samp + 16*S*C, f_pair = 200 (box model + gradient)."""
+    return Sp * B * 200 + S * 160 + 16 * S * C
+
+
+def cpu_baseline(problem, X, budget_s=10.0):
+    """The C oracle ("port") on ONE host core over a bounded sample of the same workload."""
+    from oracle import oracle as orc
+
+    orc.build()
+    orc.evaluate(problem, X[:64])
+    done, t0, chunk = 0, time.perf_counter(), 4096
+    while True:
+        lo = done % X.shape[0]
+        orc.evaluate(problem, X[lo:lo + chunk], want_grad=True, want_dist=False)
+        done += min(chunk, X.shape[0] - lo)
+        el = time.perf_counter() - t0
+        if el >= budget_s:
+            break
+    return {"value": done / el, "unit": "evals/s", "cores": 1, "kind": "port",
+            "sample": f"{done} candidates of the same batch (64 samples x 50 boxes, fp64, cost+grad), "
+                      f"{el:.1f} s of oracle/mp_oracle.c on one core of {os.cpu_count()} visible"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dtype", default="f64", choices=["f64", "f32"])
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    from motion_planning_amd import _native
+    from motion_planning_amd.batch import DeviceBatch, pack_results
+    from motion_planning_amd.synthetic import synthetic_candidates, synthetic_problem
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    else:
+        torch.cuda.set_device(0)
+    if args.gpus != world and rank == 0 and world > 1:
+        print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
+    np_dtype = np.float64 if args.dtype == "f64" else np.float32
+    tdtype = torch.float64 if args.dtype == "f64" else torch.float32
+
+    problem = synthetic_problem(_native.build_basis, N_BOXES, N_SAMPLES, seed=0)
+    Xh = synthetic_candidates(problem, N_CAND, seed=100 + rank, dtype=np_dtype)   # this rank's index shard
+    X = torch.from_numpy(Xh).cuda()
+    db = DeviceBatch(problem, N_CAND, device=local_rank if world > 1 else 0, dtype=np_dtype, want_grad=True)
+    gather_buf = [torch.empty(world * N_CAND, 3, dtype=tdtype, device="cuda") for _ in range(2)] if world > 1 else None
+    comm_stream = torch.cuda.Stream() if world > 1 else None
+
+    def step(i, pending):
+        out = db.evaluate(X)
+        if world > 1:
+            packed = pack_results(out["cost"], out["min_clear"], out["flags"])
+            ev = torch.cuda.Event()
+            ev.record()
+            with torch.cuda.stream(comm_stream):
+                comm_stream.wait_event(ev)
+                packed.record_stream(comm_stream)
+                pending.append(dist.all_gather_into_tensor(gather_buf[i % 2], packed, async_op=True))
+                if len(pending) > 2:
+                    pending.pop(0).wait()
+        return out
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    pend = []
+    for i in range(args.warmup):
+        step(i, pend)
+    for w in pend:
+        w.wait()
+    sync()
+    pend = []
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(i, pend)
+    for w in pend:
+        w.wait()
+    torch.cuda.current_stream().wait_stream(comm_stream) if world > 1 else None
+    sync()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # roofline of the dominant kernel: HIP events on the kernel's own stream, launches only
+    db.ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    db.ctx.timer_start()
+    for _ in range(args.steps):
+        db.evaluate(X)
+    kern_ms = db.ctx.timer_stop() / max(args.steps, 1)
+    flops = algorithmic_flops(N_SAMPLES, N_SAMPLES, N_BOXES, problem.n_ctrl) * N_CAND
+    peak = FP64_VALU_PEAK_TFLOPS if args.dtype == "f64" else FP32_VALU_PEAK_TFLOPS
+    achieved = flops / (kern_ms * 1e-3) / 1e12
+    es = 8 if args.dtype == "f64" else 4
+    alg_bytes = (es * problem.dim + es * (problem.dim + 2) + 1) * N_CAND
+    traffic = None
+    tfile = ROOT / "profiles" / "traffic.json"
+    if tfile.exists():
+        try:
+            traffic = json.loads(tfile.read_text()).get(f"eval_kernel_{args.dtype}_bytes_per_launch")
+        except Exception:
+            traffic = None
+
+    extras = {}
+    if rank == 0 and world == 1:
+        db_c = DeviceBatch(problem, N_CAND, dtype=np_dtype, want_grad=False)
+        db_c.evaluate(X)
+        db_c.ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+        db_c.ctx.timer_start()
+        for _ in range(args.steps):
+            db_c.evaluate(X)
+        extras["cost_only_evals_per_s"] = N_CAND / (db_c.ctx.timer_stop() / args.steps * 1e-3)
+        db_c.close()
+        other = np.float32 if args.dtype == "f64" else np.float64
+        db_o = DeviceBatch(problem, N_CAND, dtype=other, want_grad=True)
+        Xo = torch.from_numpy(Xh.astype(other)).cuda()
+        db_o.evaluate(Xo)
+        db_o.ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+        db_o.ctx.timer_start()
+        for _ in range(args.steps):
+            db_o.evaluate(Xo)
+        extras[("fp32" if args.dtype == "f64" else "fp64") + "_cost_grad_evals_per_s"] = N_CAND / (db_o.ctx.timer_stop() / args.steps * 1e-3)
+        db_o.close()
+        fl = db.flags.cpu().numpy()
+        extras["colliding_fraction"] = float((fl & 1).mean())
+        extras["feasible_fraction"] = float(((fl & 2) != 0).mean())
+
+    if rank == 0:
+        line = {
+            "metric": "spline cost+grad evals/sec (node)",
+            "value": world * N_CAND * args.steps / elapsed,
+            "unit": "evals/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": args.dtype,
+            "data": "synthetic",
+            "config": {"workload": "BASELINE config 3: 65,536 multi-start spline candidates x 64 samples x 50 axis-aligned "
+                                   "boxes per GPU, 15-term box-model cost + gradient + min clearance + flags",
+                       "candidates_per_gpu": N_CAND, "n_samples": N_SAMPLES, "n_boxes": N_BOXES, "dim": problem.dim,
+                       "parallelism": f"index-sharded x{world}, async all-gather of (cost,min_clear,flags)"},
+            "roofline": {"bound": "fp64_valu" if args.dtype == "f64" else "fp32_valu", "achieved": achieved, "peak": peak,
+                         "unit": "TFLOP/s", "frac": achieved / peak, "traffic": traffic,
+                         "kernel_ms": kern_ms, "algorithmic_flops_per_eval": flops // N_CAND,
+                         "algorithmic_bytes_per_eval": alg_bytes // N_CAND,
+                         "hbm_achieved_GBps": alg_bytes / (kern_ms * 1e-3) / 1e9, "hbm_peak_GBps": HBM_PEAK_GBPS,
+                         "note": "compute-bound on the FP64 vector ALU (no MFMA-shaped work, 145 B/eval of HBM traffic); "
+                                 "peak = datasheet FP64 vector rate"},
+            "extras": extras,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(problem, Xh.astype(np.float64))
+        print(json.dumps(line))
+    db.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

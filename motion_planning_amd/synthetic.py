@@ -21,8 +21,8 @@ class BoxList:
 
 
 def random_scene(n_boxes: int, seed: int, size_range: Tuple[float, float], start, goal) -> BoxList:
-    """Table + (n_boxes - 1) random axis-aligned boxes in [-2,2]^2 x [0,2] that do not contain
-    the start or the goal."""
+    """Table + (n_boxes - 1) random axis-aligned boxes in [-2,2]^2 x [0,2] that stay clear
+    of the moving block's start and goal poses (hence never contain start or goal)."""
     rng = np.random.default_rng(seed)
     blocks = [Block(size=(4.0, 4.0, 0.1), position=(0.0, 0.0, 0.05), object_id="table")]
     start = np.asarray(start, float)
@@ -33,7 +33,10 @@ def random_scene(n_boxes: int, seed: int, size_range: Tuple[float, float], start
         centre = lo + (hi - lo) * rng.random(3)
         size = size_range[0] + (size_range[1] - size_range[0]) * rng.random(3)
         h = 0.5 * size
-        if np.all(np.abs(start - centre) <= h) or np.all(np.abs(goal - centre) <= h):
+        # keep the start and goal poses of the moving block free at any yaw (and so the boxes
+        # never contain start/goal): half diagonal of the 0.9 x 0.6 footprint is 0.54
+        keep = np.array([0.75, 0.75, 0.45])
+        if np.all(np.abs(start - centre) <= h + keep) or np.all(np.abs(goal - centre) <= h + keep):
             continue
         blocks.append(Block(size=tuple(size.tolist()), position=tuple(centre.tolist()), object_id=f"box_{len(blocks)}"))
     return BoxList(blocks)
