@@ -149,6 +149,17 @@ __device__ __forceinline__ void pair_axes(const Pose<T> &p, T ax, T ay, T az, T 
     o.w2y = -mp_fma(c, hby, s * hbx);
 }
 
+// record `i` of a box table through the constant address space (scalar loads when i is uniform)
+template <typename T> __device__ __forceinline__ BoxRec<T> load_box_uniform(const BoxRec<T> *boxes, int i)
+{
+    typedef const T __attribute__((address_space(4))) *CPtr;
+    CPtr p = (CPtr)(unsigned long long)(boxes + i);
+    BoxRec<T> r;
+    r.cx = p[0]; r.cy = p[1]; r.cz = p[2]; r.hx = p[3]; r.hy = p[4]; r.hz = p[5];
+    r.pad0 = T(0); r.pad1 = T(0);
+    return r;
+}
+
 // scene value for one pose: min over boxes (boxes pointer and nb are wave-uniform)
 template <typename T>
 __device__ __forceinline__ T pose_distance(const Pose<T> &p, T ax, T ay, T az, const BoxRec<T> *__restrict__ boxes,
@@ -156,8 +167,13 @@ __device__ __forceinline__ T pose_distance(const Pose<T> &p, T ax, T ay, T az, c
 {
     T sep2 = Lim<T>::inf(), pen = Lim<T>::inf();
     int isep = -1, ipen = -1;
+    // The box table is read-only for the whole launch and the index is wave-uniform: read it
+    // through the constant address space so the records arrive over the scalar data path
+    // (s_load into SGPRs), and fetch record b+1 while record b is being worked on.
+    BoxRec<T> nxt = load_box_uniform(boxes, 0);
     for (int b = 0; b < nb; ++b) {
-        const BoxRec<T> bx = boxes[b];
+        const BoxRec<T> bx = nxt;
+        nxt = load_box_uniform(boxes, b + 1 < nb ? b + 1 : b);
         PairOut<T> o;
         pair_axes(p, ax, ay, az, bx.cx, bx.cy, bx.cz, bx.hx, bx.hy, bx.hz, o);
         const bool xy_sep = o.gsat > T(0);

@@ -201,7 +201,7 @@ def test_scene_class_queries(oracle_lib):
     d_ign = s.signed_distance_block((0.6, 0.9, 0.6), (0.0, 0.25, 0.4), yaw_deg_to_quat(90.0), ignore_ids=["cube_top", "table"])
     assert d_ign == pytest.approx(1.0 - 0.05 - 0.45, abs=1e-12)
     (xs, ys, zs), grid = s.sample_sdf_grid(((-1, 1), (-1, 1), (0, 2)), (5, 4, 3))
-    assert grid.shape == (5, 4, 3) and grid[2, 1, 0] < 0
+    assert grid.shape == (5, 4, 3) and grid[2, 1, 0] <= 0
     assert Scene().signed_distance_block((1, 1, 1), (0, 0, 0)) == np.inf
 
 
