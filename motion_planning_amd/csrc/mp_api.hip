@@ -35,7 +35,8 @@ struct mp_ctx {
     size_t max_lds = 65536;
 
     // scene
-    DevBuf boxes;
+    DevBuf boxes, boxes32;
+    float scene_radius = 0.f;
     int n_boxes = 0;
     bool have_scene = false;
 
@@ -200,6 +201,15 @@ template <typename T> int upload_scene(mp_ctx *ctx, int n, const double *cx, con
     }
     int rc = upload(ctx, ctx->boxes, rec.data(), (size_t)n * sizeof(mp::BoxRec<T>));
     if (rc) return rc;
+    // fp32 copy for the conservative bound pass + the scene radius its slack is scaled with
+    std::vector<mp::BoxRec32> rec32((size_t)std::max(n, 1));
+    double radius = 0.0;
+    for (int i = 0; i < n; ++i) {
+        rec32[i] = mp::BoxRec32{(float)cx[i], (float)cy[i], (float)cz[i], (float)hx[i], (float)hy[i], (float)hz[i], 0.f, 0.f};
+        radius = std::max({radius, std::fabs(cx[i]) + hx[i], std::fabs(cy[i]) + hy[i], std::fabs(cz[i]) + hz[i]});
+    }
+    ctx->scene_radius = (float)radius;
+    if ((rc = upload(ctx, ctx->boxes32, rec32.data(), (size_t)n * sizeof(mp::BoxRec32)))) return rc;
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));  // rec is a local
     return MP_OK;
 }
@@ -256,7 +266,7 @@ int launch_eval(mp_ctx *ctx, long long n, const void *X, const int32_t *task_of,
     a.nyf = c.n_yaw_free; a.Sp = c.n_safe; a.last_cond = c.last_if_not_close; a.keep_n = c.keep_n;
     a.use_pref = c.use_pref; a.tail_start = c.tail_start; a.use_goal_target = c.use_goal_target;
     a.goal_tail_n = c.goal_tail_n; a.mask = c.term_mask;
-    a.lds_per_wave = mp::lds_units_per_wave(c.n_samples);
+    a.lds_per_wave = mp::lds_bytes_per_wave(c.n_samples, (int)sizeof(T));
     a.n_tasks = ctx->n_tasks;
     for (int i = 0; i < MP_NTERMS; ++i) a.w[i] = (T)c.weights[i];
     a.req = (T)c.required_clearance; a.pref = (T)c.preferred_clearance; a.appr_tgt = (T)c.approach_target;
@@ -265,11 +275,12 @@ int launch_eval(mp_ctx *ctx, long long n, const void *X, const int32_t *task_of,
     a.idx_safe = (const int *)ctx->d_idx.p; a.amask = (const uint8_t *)ctx->d_mask.p;
     a.M = (const T *)ctx->d_M.p; a.My = (const T *)ctx->d_My.p; a.tsched = (const T *)ctx->d_tsched.p;
     a.tasks = (const mp::DevTask<T> *)ctx->d_tasks.p; a.boxes = (const mp::BoxRec<T> *)ctx->boxes.p;
+    a.boxes32 = (const mp::BoxRec32 *)ctx->boxes32.p; a.scene_radius = ctx->scene_radius;
     a.X = (const T *)X; a.task_of = task_of; a.cpt = ctx->cands_per_task; a.n = n;
     a.cost = (T *)cost; a.terms = (T *)terms; a.grad = (T *)grad; a.minc = (T *)minc; a.dist = (T *)dist;
     a.flags = flags;
 
-    const size_t per_wave = (size_t)a.lds_per_wave * sizeof(T);
+    const size_t per_wave = (size_t)a.lds_per_wave;
     int wpb = (int)std::min<size_t>(4, std::max<size_t>(1, 65536 / per_wave));
     const size_t lds_bytes = per_wave * wpb;
     if (lds_bytes > ctx->max_lds)
@@ -340,7 +351,7 @@ int mp_destroy(mp_ctx *ctx)
     if (!ctx) return MP_OK;
     hipSetDevice(ctx->device);
     hipStreamSynchronize(ctx->stream);
-    DevBuf *bufs[] = {&ctx->boxes, &ctx->d_idx, &ctx->d_mask, &ctx->d_M, &ctx->d_My, &ctx->d_tsched, &ctx->d_tasks,
+    DevBuf *bufs[] = {&ctx->boxes, &ctx->boxes32, &ctx->d_idx, &ctx->d_mask, &ctx->d_M, &ctx->d_My, &ctx->d_tsched, &ctx->d_tasks,
                       &ctx->s_X, &ctx->s_taskof, &ctx->s_cost, &ctx->s_terms, &ctx->s_grad, &ctx->s_minc,
                       &ctx->s_flags, &ctx->s_dist, &ctx->s_aux0, &ctx->s_aux1};
     for (DevBuf *b : bufs)

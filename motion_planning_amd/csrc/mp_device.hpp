@@ -205,6 +205,90 @@ __device__ __forceinline__ T pose_distance(const Pose<T> &p, T ax, T ay, T az, c
     return mp_sqrt(sep2);
 }
 
+// ---- culled clearance: conservative fp32 bound + exact evaluation of the survivors ---------
+// Ordering key of one exact pair result, so that a single 64-bit unsigned min implements
+// "any overlap beats every separation; deepest overlap / smallest squared distance wins":
+//   overlapping (value pen <= 0): K = bits(+inf) - bits(|pen|)          (top bit clear)
+//   separated   (value v2  >= 0): K = 2^63 | bits(v2)                    (top bit set)
+template <typename T> struct Key;
+template <> struct Key<double> {
+    static constexpr unsigned long long kInfBits = 0x7ff0000000000000ull;
+    __device__ static unsigned long long bits(double v) { return (unsigned long long)__double_as_longlong(v); }
+    __device__ static double from_bits(unsigned long long b) { return __longlong_as_double((long long)b); }
+};
+template <> struct Key<float> {
+    static constexpr unsigned long long kInfBits = 0x7f800000ull;
+    __device__ static unsigned long long bits(float v) { return (unsigned long long)__float_as_uint(v); }
+    __device__ static float from_bits(unsigned long long b) { return __uint_as_float((unsigned int)b); }
+};
+constexpr unsigned long long kSepBit = 0x8000000000000000ull;
+
+template <typename T> __device__ __forceinline__ unsigned long long key_init()
+{
+    return kSepBit | Key<T>::kInfBits;  // separated by +inf: the value of an empty scene
+}
+template <typename T> __device__ __forceinline__ T key_to_distance(unsigned long long k)
+{
+    if (k & kSepBit) return mp_sqrt(Key<T>::from_bits(k & ~kSepBit));
+    return -Key<T>::from_bits(Key<T>::kInfBits - k);
+}
+// squared separation encoded in the key, 0 for an overlap (upper bound used by the culling)
+template <typename T> __device__ __forceinline__ T key_to_sep2(unsigned long long k)
+{
+    return (k & kSepBit) ? Key<T>::from_bits(k & ~kSepBit) : T(0);
+}
+
+// exact result of one (pose, box) pair as a key; same arithmetic as the brute-force loop
+template <typename T>
+__device__ __forceinline__ unsigned long long pair_key(const Pose<T> &p, T ax, T ay, T az, T bcx, T bcy, T bcz, T hbx,
+                                                        T hby, T hbz)
+{
+    PairOut<T> o;
+    pair_axes(p, ax, ay, az, bcx, bcy, bcz, hbx, hby, hbz, o);
+    const bool xy_sep = o.gsat > T(0);
+    const bool separated = xy_sep || o.gz > T(0);
+    T v = rect_d2(o.dx + p.u1x, o.dy + p.u1y, hbx, hby);
+    v = mp_min(v, rect_d2(o.dx - p.u1x, o.dy - p.u1y, hbx, hby));
+    v = mp_min(v, rect_d2(o.dx + p.u2x, o.dy + p.u2y, hbx, hby));
+    v = mp_min(v, rect_d2(o.dx - p.u2x, o.dy - p.u2y, hbx, hby));
+    v = mp_min(v, rect_d2(o.lx - o.w1x, o.ly - o.w1y, ax, ay));
+    v = mp_min(v, rect_d2(o.lx + o.w1x, o.ly + o.w1y, ax, ay));
+    v = mp_min(v, rect_d2(o.lx - o.w2x, o.ly - o.w2y, ax, ay));
+    v = mp_min(v, rect_d2(o.lx + o.w2x, o.ly + o.w2y, ax, ay));
+    T dxy2 = xy_sep ? v : T(0);
+    T zs = mp_max(o.gz, T(0));
+    T v2 = mp_fma(zs, zs, dxy2);
+    T pn = mp_max(o.gsat, o.gz);
+    unsigned long long ks = kSepBit | Key<T>::bits(v2);
+    unsigned long long kp = Key<T>::kInfBits - Key<T>::bits(mp_abs(pn));
+    return separated ? ks : kp;
+}
+
+// fp32 record of a box for the bound pass
+struct BoxRec32 { float cx, cy, cz, hx, hy, hz, pad0, pad1; };
+
+__device__ __forceinline__ BoxRec32 load_box32_uniform(const BoxRec32 *boxes, int i)
+{
+    typedef const float __attribute__((address_space(4))) *CPtr;
+    CPtr p = (CPtr)(unsigned long long)(boxes + i);
+    BoxRec32 r;
+    r.cx = p[0]; r.cy = p[1]; r.cz = p[2]; r.hx = p[3]; r.hy = p[4]; r.hz = p[5];
+    r.pad0 = 0.f; r.pad1 = 0.f;
+    return r;
+}
+
+// Conservative lower bound (fp32) of the squared distance between the mover's world AABB and a
+// box: the three world-axis SAT gaps, each deflated by `slack` (folded into ex/ey/ez by the
+// caller) so that fp32 rounding can never lift the bound above the exactly evaluated value.
+__device__ __forceinline__ float aabb_lb2(float px, float py, float pz, float exs, float eys, float ezs, const BoxRec32 &b)
+{
+    float qx = __builtin_fabsf(px - b.cx) - (b.hx + exs);
+    float qy = __builtin_fabsf(py - b.cy) - (b.hy + eys);
+    float qz = __builtin_fabsf(pz - b.cz) - (b.hz + ezs);
+    float mx = __builtin_fmaxf(qx, 0.f), my = __builtin_fmaxf(qy, 0.f), mz = __builtin_fmaxf(qz, 0.f);
+    return __builtin_fmaf(mz, mz, __builtin_fmaf(my, my, mx * mx));
+}
+
 // d(pair)/d(px,py,pz,theta[rad]) for the deciding box (mirrors the oracle's pair_grad)
 template <typename T>
 __device__ __forceinline__ void pair_grad(const Pose<T> &p, T ax, T ay, T az, const BoxRec<T> bx, T &g0, T &g1,

@@ -23,7 +23,7 @@ template <typename T> struct DevTask {
 template <typename T> struct EvalArgs {
     int S, C, ff, nf, Cy, nyf, Sp, last_cond, keep_n, use_pref, tail_start, use_goal_target, goal_tail_n;
     unsigned mask;
-    int lds_per_wave;  // in units of T
+    int lds_per_wave;  // bytes
     int n_tasks;
     T w[kNTerms];
     T req, pref, appr_tgt, goal_tgt, radius, ax, ay, az;
@@ -34,6 +34,8 @@ template <typename T> struct EvalArgs {
     const T *tsched;
     const DevTask<T> *tasks;
     const BoxRec<T> *boxes;
+    const BoxRec32 *boxes32;  // fp32 copy of the box table for the bound pass
+    float scene_radius;       // max |centre| + half extent over the scene (slack of the bound)
     const T *X;
     const int *task_of;
     long long cpt;
@@ -42,9 +44,16 @@ template <typename T> struct EvalArgs {
     uint8_t *flags;
 };
 
-// LDS slice of one wave, in units of T.  Layout (S = samples):
-//   W[64] | P[3][S] YAW[S] | GP[3][S] GY[S] | D[S] GD[S] | CC[S] SS[S] | D1[3][S] A1[3][S] A2[3][S] | ARG[S] (int)
-__host__ __device__ inline int lds_units_per_wave(int S) { return 64 + 22 * S; }
+// LDS slice of one wave (bytes).  Layout (S = samples, e = sizeof(T)):
+//   W[64] | P[3][S] YAW[S] | GP[3][S] GY[S] | D[S] GD[S] | CC[S] SS[S] | D1[3][S] A1[3][S] A2[3][S]   (T)
+//   | MINKEY[S] (u64) | ARG[S] (int) | QUEUE[128] (u32)
+__host__ __device__ inline int lds_bytes_per_wave(int S, int e)
+{
+    int b = (64 + 21 * S) * e;
+    b = (b + 7) & ~7;
+    b += 8 * S + 4 * S + 4 * 128;
+    return (b + 15) & ~15;
+}
 
 template <typename T, int MODEL, bool GRAD>
 __global__ void __launch_bounds__(256) eval_kernel(const EvalArgs<T> a)
@@ -55,7 +64,7 @@ __global__ void __launch_bounds__(256) eval_kernel(const EvalArgs<T> a)
     const int wpb = (int)(blockDim.x >> 6);
     const int S = a.S, C = a.C, Cy = a.Cy, nf = a.nf, ff = a.ff, nyf = a.nyf;
     const int D = 3 * nf + nyf;
-    T *base = reinterpret_cast<T *>(smem_raw) + (size_t)wib * a.lds_per_wave;
+    T *base = reinterpret_cast<T *>(smem_raw + (size_t)wib * a.lds_per_wave);
     T *W = base;
     T *P0 = W + 64, *P1 = P0 + S, *P2 = P1 + S, *YW = P2 + S;
     T *G0 = YW + S, *G1 = G0 + S, *G2 = G1 + S, *GY = G2 + S;
@@ -64,7 +73,10 @@ __global__ void __launch_bounds__(256) eval_kernel(const EvalArgs<T> a)
     T *D1x = SS + S, *D1y = D1x + S, *D1z = D1y + S;
     T *A1x = D1z + S, *A1y = A1x + S, *A1z = A1y + S;
     T *A2x = A1z + S, *A2y = A2x + S, *A2z = A2y + S;
-    int *ARG = reinterpret_cast<int *>(A2z + S);
+    unsigned long long *MINKEY =
+        reinterpret_cast<unsigned long long *>(smem_raw + (size_t)wib * a.lds_per_wave + (((64 + 21 * S) * sizeof(T) + 7) & ~(size_t)7));
+    int *ARG = reinterpret_cast<int *>(MINKEY + S);
+    unsigned int *QUEUE = reinterpret_cast<unsigned int *>(ARG + S);
     const unsigned mask = a.mask;
     const T du = T(1) / (T)(S - 1);
     const T inv_du = T(1);  // (unused placeholder to keep the reference's division form)
@@ -198,23 +210,101 @@ __global__ void __launch_bounds__(256) eval_kernel(const EvalArgs<T> a)
 
         // ---- clearance profile d_safe ----
         int Sp = a.Sp;
-        for (int k = lane; k < Sp; k += 64) {
-            const int s = a.idx_safe[k];
-            int arg = -1;
-            T d;
-            if (MODEL == 1) {
-                T c, sn;
-                yaw_rot(YW[s], c, sn);
-                Pose<T> ps;
-                pose_setup(ps, P0[s], P1[s], P2[s], c, sn, a.ax, a.ay);
-                d = pose_distance(ps, a.ax, a.ay, a.az, boxes, nb, arg);
-                CC[k] = c; SS[k] = sn;
-            } else {
-                d = point_distance(P0[s], P1[s], P2[s], boxes, nb, a.radius, arg);
+        if (MODEL == 1) {
+            const BoxRec32 *boxes32 = a.boxes32 + tk.box_begin;
+            const float ax32 = (float)a.ax, ay32 = (float)a.ay, az32 = (float)a.az;
+            for (int k0 = 0; k0 < Sp; k0 += 64) {
+                // this lane's own collision sample
+                const int k = k0 + lane;
+                const bool valid = k < Sp;
+                float px32 = 0.f, py32 = 0.f, pz32 = 0.f, exs = 0.f, eys = 0.f, ezs = 0.f;
+                if (valid) {
+                    const int s = a.idx_safe[k];
+                    T c, sn;
+                    yaw_rot(YW[s], c, sn);
+                    CC[k] = c; SS[k] = sn;
+                    MINKEY[k] = key_init<T>();
+                    ARG[k] = -1;
+                    px32 = (float)P0[s]; py32 = (float)P1[s]; pz32 = (float)P2[s];
+                    const float c32 = __builtin_fabsf((float)c), s32 = __builtin_fabsf((float)sn);
+                    const float slack = 2e-6f * (__builtin_fabsf(px32) + __builtin_fabsf(py32) + __builtin_fabsf(pz32) +
+                                                 a.scene_radius + ax32 + ay32 + az32) + 1e-30f;
+                    exs = __builtin_fmaf(s32, ay32, c32 * ax32) + slack;
+                    eys = __builtin_fmaf(c32, ay32, s32 * ax32) + slack;
+                    ezs = az32 + slack;
+                }
+                float U32 = __builtin_huge_valf();
+                int qhead = 0, qcount = 0;  // wave-uniform
+
+                // exact evaluation of up to 64 queued (sample, box) pairs, one per lane
+                auto drain = [&](int cnt) {
+                    wave_lds_sync();
+                    const bool act = lane < cnt;
+                    unsigned long long key = ~0ull, oldk = 0ull;
+                    int kk = 0, bb = 0;
+                    if (act) {
+                        const unsigned int e = QUEUE[(qhead + lane) & 127];
+                        kk = k0 + (int)(e >> 24);
+                        bb = (int)(e & 0xffffffu);
+                        const int ss = a.idx_safe[kk];
+                        Pose<T> ps;
+                        pose_setup(ps, P0[ss], P1[ss], P2[ss], CC[kk], SS[kk], a.ax, a.ay);
+                        const BoxRec<T> bx = boxes[bb];
+                        key = pair_key(ps, a.ax, a.ay, a.az, bx.cx, bx.cy, bx.cz, bx.hx, bx.hy, bx.hz);
+                        oldk = MINKEY[kk];
+                    }
+                    wave_lds_sync();
+                    if (act) atomicMin(&MINKEY[kk], key);
+                    wave_lds_sync();
+                    bool win = false;
+                    if (act) {
+                        const unsigned long long newk = MINKEY[kk];
+                        win = key == newk;
+                        if (win && newk < oldk) ARG[kk] = 0x7fffffff;  // strictly better: restart the argmin
+                    }
+                    wave_lds_sync();
+                    if (win) atomicMin(&ARG[kk], bb);  // ties: lowest box index, like a first-minimum scan
+                    wave_lds_sync();
+                    if (valid) U32 = (float)key_to_sep2<T>(MINKEY[k]) * (1.0f + 4e-6f);
+                };
+
+                BoxRec32 nxt = load_box32_uniform(boxes32, 0);
+                for (int b = 0; b < nb; ++b) {
+                    const BoxRec32 bx = nxt;
+                    nxt = load_box32_uniform(boxes32, b + 1 < nb ? b + 1 : b);
+                    const float lb2 = aabb_lb2(px32, py32, pz32, exs, eys, ezs, bx);
+                    const bool need = valid && (lb2 <= U32);
+                    const unsigned long long m = __builtin_amdgcn_ballot_w64(need);
+                    if (m) {
+                        if (need) {
+                            const int pos = __builtin_amdgcn_mbcnt_hi((unsigned int)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)m, 0u));
+                            QUEUE[(qhead + qcount + pos) & 127] = ((unsigned int)lane << 24) | (unsigned int)b;
+                        }
+                        qcount += __builtin_popcountll(m);
+                        if (qcount >= 64) {
+                            drain(64);
+                            qhead = (qhead + 64) & 127;
+                            qcount -= 64;
+                        }
+                    }
+                }
+                if (qcount > 0) drain(qcount);
+                wave_lds_sync();
+                if (valid) {
+                    const T d = key_to_distance<T>(MINKEY[k]);
+                    Dd[k] = d;
+                    if (a.dist) a.dist[cand * a.Sp + k] = d;
+                }
             }
-            Dd[k] = d;
-            ARG[k] = arg;
-            if (a.dist) a.dist[cand * a.Sp + k] = d;
+        } else {
+            for (int k = lane; k < Sp; k += 64) {
+                const int s = a.idx_safe[k];
+                int arg = -1;
+                const T d = point_distance(P0[s], P1[s], P2[s], boxes, nb, a.radius, arg);
+                Dd[k] = d;
+                ARG[k] = arg;
+                if (a.dist) a.dist[cand * a.Sp + k] = d;
+            }
         }
         wave_lds_sync();
         if (a.last_cond && Sp >= 2) {  // P[::k] + conditional last sample (spline_opt.py:802-805)
