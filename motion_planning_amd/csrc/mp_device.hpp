@@ -321,7 +321,8 @@ __device__ __forceinline__ void pair_grad(const Pose<T> &p, T ax, T ay, T az, co
         T zs = mp_max(o.gz, T(0));
         T d = mp_sqrt(mp_fma(zs, zs, dxy2));
         if (!(d > T(0))) return;
-        if (o.gz > T(0)) g2 = sgn(o.dz) * o.gz / d;
+        const T inv_d = T(1) / d;
+        if (o.gz > T(0)) g2 = sgn(o.dz) * o.gz * inv_d;
         if (!xy_sep) return;
         if (f < 4) {
             T rx = (f < 2) ? p.u1x : p.u2x, ry = (f < 2) ? p.u1y : p.u2y;
@@ -330,9 +331,9 @@ __device__ __forceinline__ void pair_grad(const Pose<T> &p, T ax, T ay, T az, co
             T qx = mp_abs(X) - bx.hx, qy = mp_abs(Y) - bx.hy;
             T mx = qx > T(0) ? sgn(X) * qx : T(0);
             T my = qy > T(0) ? sgn(Y) * qy : T(0);
-            g0 = mx / d;
-            g1 = my / d;
-            g3 = (my * rx - mx * ry) / d;
+            g0 = mx * inv_d;
+            g1 = my * inv_d;
+            g3 = (my * rx - mx * ry) * inv_d;
         } else {
             T wx = (f < 6) ? o.w1x : o.w2x, wy = (f < 6) ? o.w1y : o.w2y;
             if (!(f & 1)) { wx = -wx; wy = -wy; }
@@ -340,9 +341,9 @@ __device__ __forceinline__ void pair_grad(const Pose<T> &p, T ax, T ay, T az, co
             T qx = mp_abs(tx) - ax, qy = mp_abs(ty) - ay;
             T mx = qx > T(0) ? sgn(tx) * qx : T(0);
             T my = qy > T(0) ? sgn(ty) * qy : T(0);
-            g0 = (c * mx - s * my) / d;
-            g1 = (s * mx + c * my) / d;
-            g3 = (mx * ty - my * tx) / d;
+            g0 = (c * mx - s * my) * inv_d;
+            g1 = (s * mx + c * my) * inv_d;
+            g3 = (mx * ty - my * tx) * inv_d;
         }
     } else {
         int a = 0;
@@ -429,26 +430,49 @@ __device__ __forceinline__ void wave_lds_sync()
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-__device__ __forceinline__ double wave_sum(double v)
+// Cross-lane moves through the DPP network (no LDS round trip).  A 64-bit value moves as two dwords.
+template <int CTRL, int ROW_MASK, bool ZERO_FILL> __device__ __forceinline__ int dpp32(int v)
 {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-    return v;
+    return __builtin_amdgcn_update_dpp(ZERO_FILL ? 0 : v, v, CTRL, ROW_MASK, 0xf, ZERO_FILL);
 }
-__device__ __forceinline__ float wave_sum(float v)
+template <int CTRL, int ROW_MASK, bool ZERO_FILL> __device__ __forceinline__ float dpp_mov(float v)
 {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-    return v;
+    return __int_as_float(dpp32<CTRL, ROW_MASK, ZERO_FILL>(__float_as_int(v)));
 }
+template <int CTRL, int ROW_MASK, bool ZERO_FILL> __device__ __forceinline__ double dpp_mov(double v)
+{
+    int lo = dpp32<CTRL, ROW_MASK, ZERO_FILL>(__double2loint(v));
+    int hi = dpp32<CTRL, ROW_MASK, ZERO_FILL>(__double2hiint(v));
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ float read_lane63(float v) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63)); }
+__device__ __forceinline__ double read_lane63(double v)
+{
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), 63), __builtin_amdgcn_readlane(__double2loint(v), 63));
+}
+
+// Sum over the 64 lanes, result wave-uniform.  quad swaps -> half-row mirror -> row mirror give every
+// lane its row total; row_bcast:15 / row_bcast:31 carry the totals up to lane 63.
+template <typename T> __device__ __forceinline__ T wave_sum(T v)
+{
+    v += dpp_mov<0xB1, 0xf, true>(v);   // quad_perm [1,0,3,2]
+    v += dpp_mov<0x4E, 0xf, true>(v);   // quad_perm [2,3,0,1]
+    v += dpp_mov<0x141, 0xf, true>(v);  // row_half_mirror
+    v += dpp_mov<0x140, 0xf, true>(v);  // row_mirror
+    v += dpp_mov<0x142, 0xa, true>(v);  // row_bcast:15 into rows 1 and 3
+    v += dpp_mov<0x143, 0xc, true>(v);  // row_bcast:31 into rows 2 and 3
+    return read_lane63(v);
+}
+template <typename T> __device__ __forceinline__ T lane_min(T a, T b) { return b < a ? b : a; }
 template <typename T> __device__ __forceinline__ T wave_min(T v)
 {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        T o = __shfl_xor(v, off, 64);
-        v = o < v ? o : v;
-    }
-    return v;
+    v = lane_min(v, dpp_mov<0xB1, 0xf, false>(v));
+    v = lane_min(v, dpp_mov<0x4E, 0xf, false>(v));
+    v = lane_min(v, dpp_mov<0x141, 0xf, false>(v));
+    v = lane_min(v, dpp_mov<0x140, 0xf, false>(v));
+    v = lane_min(v, dpp_mov<0x142, 0xa, false>(v));
+    v = lane_min(v, dpp_mov<0x143, 0xc, false>(v));
+    return read_lane63(v);
 }
 
 }  // namespace mp

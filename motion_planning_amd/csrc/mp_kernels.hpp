@@ -45,11 +45,11 @@ template <typename T> struct EvalArgs {
 };
 
 // LDS slice of one wave (bytes).  Layout (S = samples, e = sizeof(T)):
-//   W[64] | P[3][S] YAW[S] | GP[3][S] GY[S] | D[S] GD[S] | CC[S] SS[S] | D1[3][S] A1[3][S] A2[3][S]   (T)
+//   W[64] | P[3][S] YAW[S] | GP[3][S] GY[S] | D[S] GD[S] | CC[S] SS[S] | D1[3][S] A1[3][S] A2[3][S] SEGW[S]   (T)
 //   | MINKEY[S] (u64) | ARG[S] (int) | QUEUE[128] (u32)
 __host__ __device__ inline int lds_bytes_per_wave(int S, int e)
 {
-    int b = (64 + 21 * S) * e;
+    int b = (64 + 22 * S) * e;
     b = (b + 7) & ~7;
     b += 8 * S + 4 * S + 4 * 128;
     return (b + 15) & ~15;
@@ -73,14 +73,15 @@ __global__ void __launch_bounds__(256) eval_kernel(const EvalArgs<T> a)
     T *D1x = SS + S, *D1y = D1x + S, *D1z = D1y + S;
     T *A1x = D1z + S, *A1y = A1x + S, *A1z = A1y + S;
     T *A2x = A1z + S, *A2y = A2x + S, *A2z = A2y + S;
+    T *SEGW = A2z + S;
     unsigned long long *MINKEY =
-        reinterpret_cast<unsigned long long *>(smem_raw + (size_t)wib * a.lds_per_wave + (((64 + 21 * S) * sizeof(T) + 7) & ~(size_t)7));
+        reinterpret_cast<unsigned long long *>(smem_raw + (size_t)wib * a.lds_per_wave + (((64 + 22 * S) * sizeof(T) + 7) & ~(size_t)7));
     int *ARG = reinterpret_cast<int *>(MINKEY + S);
     unsigned int *QUEUE = reinterpret_cast<unsigned int *>(ARG + S);
     const unsigned mask = a.mask;
     const T du = T(1) / (T)(S - 1);
-    const T inv_du = T(1);  // (unused placeholder to keep the reference's division form)
-    (void)inv_du;
+    // the stencils of np.gradient multiply by these instead of dividing by du / 2du (<= 1 ulp apart)
+    const T inv_du = T(1) / du, inv_h2 = T(1) / (T(2) * du);
 
     for (long long cand = (long long)blockIdx.x * wpb + wib; cand < a.n; cand += (long long)gridDim.x * wpb) {
         long long tl = a.task_of ? (long long)a.task_of[cand] : (a.cpt > 0 ? cand / a.cpt : 0);
@@ -132,7 +133,9 @@ __global__ void __launch_bounds__(256) eval_kernel(const EvalArgs<T> a)
             const T px = P0[s], py = P1[s], pz = P2[s], yw = YW[s];
             if (s + 1 < S) {
                 T ex = P0[s + 1] - px, ey = P1[s + 1] - py, ez = P2[s + 1] - pz;
-                t_len += mp_sqrt(ex * ex + ey * ey + ez * ez);
+                T n = mp_sqrt(ex * ex + ey * ey + ez * ez);
+                t_len += n;
+                if (GRAD) SEGW[s] = n > T(0) ? a.w[0] / n : T(0);  // w_len / |segment s|, reused by the reverse sweep
                 T dy = YW[s + 1] - yw;
                 T e = npmax0(tk.yaw_inc ? -dy : dy);
                 t_mono += e * e;
@@ -146,18 +149,10 @@ __global__ void __launch_bounds__(256) eval_kernel(const EvalArgs<T> a)
                 T e = yw - target;
                 t_sched += e * e;
             }
-            if (S >= 3) {  // np.gradient(P, du)
-                T gx, gy, gz;
-                if (s == 0) {
-                    gx = (P0[1] - px) / du; gy = (P1[1] - py) / du; gz = (P2[1] - pz) / du;
-                } else if (s == S - 1) {
-                    gx = (px - P0[s - 1]) / du; gy = (py - P1[s - 1]) / du; gz = (pz - P2[s - 1]) / du;
-                } else {
-                    const T h2 = T(2) * du;
-                    gx = (P0[s + 1] - P0[s - 1]) / h2; gy = (P1[s + 1] - P1[s - 1]) / h2;
-                    gz = (P2[s + 1] - P2[s - 1]) / h2;
-                }
-                D1x[s] = gx; D1y[s] = gy; D1z[s] = gz;
+            if (S >= 3) {  // np.gradient(P, du): one-sided at the ends, central inside
+                const int lo = s == 0 ? 0 : s - 1, hi = s == S - 1 ? s : s + 1;
+                const T sc = (s == 0 || s == S - 1) ? inv_du : inv_h2;
+                D1x[s] = (P0[hi] - P0[lo]) * sc; D1y[s] = (P1[hi] - P1[lo]) * sc; D1z[s] = (P2[hi] - P2[lo]) * sc;
             }
         }
         wave_lds_sync();
@@ -166,39 +161,36 @@ __global__ void __launch_bounds__(256) eval_kernel(const EvalArgs<T> a)
             const T eps = T(1e-9);
             for (int s = lane; s < S; s += 64) {
                 const T v1x = D1x[s], v1y = D1y[s], v1z = D1z[s];
-                T v2x, v2y, v2z;
-                if (s == 0) {
-                    v2x = (D1x[1] - v1x) / du; v2y = (D1y[1] - v1y) / du; v2z = (D1z[1] - v1z) / du;
-                } else if (s == S - 1) {
-                    v2x = (v1x - D1x[s - 1]) / du; v2y = (v1y - D1y[s - 1]) / du; v2z = (v1z - D1z[s - 1]) / du;
-                } else {
-                    const T h2 = T(2) * du;
-                    v2x = (D1x[s + 1] - D1x[s - 1]) / h2; v2y = (D1y[s + 1] - D1y[s - 1]) / h2;
-                    v2z = (D1z[s + 1] - D1z[s - 1]) / h2;
-                }
+                const int lo = s == 0 ? 0 : s - 1, hi = s == S - 1 ? s : s + 1;
+                const T sc = (s == 0 || s == S - 1) ? inv_du : inv_h2;
+                const T v2x = (D1x[hi] - D1x[lo]) * sc, v2y = (D1y[hi] - D1y[lo]) * sc, v2z = (D1z[hi] - D1z[lo]) * sc;
                 T speed = mp_sqrt(v1x * v1x + v1y * v1y + v1z * v1z);
                 T cx = v1y * v2z - v1z * v2y, cy = v1z * v2x - v1x * v2z, cz = v1x * v2y - v1y * v2x;
-                T cn = mp_sqrt(cx * cx + cy * cy + cz * cz);
+                T cn2 = cx * cx + cy * cy + cz * cz;
+                T cn = mp_sqrt(cn2);
                 T sp = speed > eps ? speed : eps;
-                T sp3 = sp * sp * sp;
-                T kappa = cn / sp3;
+                T inv_sp = T(1) / sp;
+                T inv_sp3 = inv_sp * inv_sp * inv_sp;
+                T kappa = cn * inv_sp3;
                 t_curv += (kappa * kappa) * speed;
                 if (GRAD) {
-                    T sp6 = sp3 * sp3;
-                    T k = a.w[1] * du;
-                    T f2 = k * T(2) * speed / sp6;
-                    T gcx = f2 * cx, gcy = f2 * cy, gcz = f2 * cz;
-                    T gs = cn * cn / sp6;
-                    if (speed > eps) gs += T(-6) * cn * cn * speed / (sp6 * sp);
-                    gs *= k;
-                    T g1x = v2y * gcz - v2z * gcy, g1y = v2z * gcx - v2x * gcz, g1z = v2x * gcy - v2y * gcx;
-                    T g2x = gcy * v1z - gcz * v1y, g2y = gcz * v1x - gcx * v1z, g2z = gcx * v1y - gcy * v1x;
-                    if (speed > T(0)) {
-                        T q = gs / speed;
-                        g1x += q * v1x; g1y += q * v1y; g1z += q * v1z;
+                    // f = |c|^2 speed / sp^6 with c = d1 x d2; adjoints of d1 and d2
+                    const T inv_sp6 = inv_sp3 * inv_sp3;
+                    const T k = a.w[1] * du;
+                    const T f2 = k * T(2) * speed * inv_sp6;
+                    const T gcx = f2 * cx, gcy = f2 * cy, gcz = f2 * cz;
+                    T gs = cn2 * inv_sp6;
+                    T q = T(0);
+                    if (speed > eps) {
+                        gs = gs + T(-6) * gs;  // explicit + through sp (= speed)
+                        q = k * gs * inv_sp;
+                    } else if (speed > T(0)) {
+                        q = k * gs / speed;
                     }
-                    A1x[s] = g1x; A1y[s] = g1y; A1z[s] = g1z;
-                    A2x[s] = g2x; A2y[s] = g2y; A2z[s] = g2z;
+                    A1x[s] = v2y * gcz - v2z * gcy + q * v1x;
+                    A1y[s] = v2z * gcx - v2x * gcz + q * v1y;
+                    A1z[s] = v2x * gcy - v2y * gcx + q * v1z;
+                    A2x[s] = gcy * v1z - gcz * v1y; A2y[s] = gcz * v1x - gcx * v1z; A2z[s] = gcx * v1y - gcy * v1x;
                 }
             }
         } else if (GRAD) {
@@ -468,20 +460,18 @@ __global__ void __launch_bounds__(256) eval_kernel(const EvalArgs<T> a)
                     }
                 }
             }
-            // (2) curvature: T1 = A1 + G^T A2 (kept in D1*)
+            // (2) curvature: T1 = A1 + G^T A2 (kept in D1*).  (G^T v)[s] = cm v[s-1] + c0 v[s] + cp v[s+1]
+            // with the transposed np.gradient coefficients of row s (ends one-sided, inside central).
             const bool curv = (mask & 2u) && S >= 3;
             if (curv) {
                 for (int s = lane; s < S; s += 64) {
-                    // (G^T v)[s]
-                    T tx = T(0), ty = T(0), tz = T(0);
-                    const T h2 = T(2) * du;
-                    if (s == 0) { tx -= A2x[0] / du; ty -= A2y[0] / du; tz -= A2z[0] / du; }
-                    if (s == 1) { tx += A2x[0] / du; ty += A2y[0] / du; tz += A2z[0] / du; }
-                    if (s == S - 2) { tx -= A2x[S - 1] / du; ty -= A2y[S - 1] / du; tz -= A2z[S - 1] / du; }
-                    if (s == S - 1) { tx += A2x[S - 1] / du; ty += A2y[S - 1] / du; tz += A2z[S - 1] / du; }
-                    if (s - 1 >= 1 && s - 1 <= S - 2) { tx += A2x[s - 1] / h2; ty += A2y[s - 1] / h2; tz += A2z[s - 1] / h2; }
-                    if (s + 1 >= 1 && s + 1 <= S - 2) { tx -= A2x[s + 1] / h2; ty -= A2y[s + 1] / h2; tz -= A2z[s + 1] / h2; }
-                    D1x[s] = A1x[s] + tx; D1y[s] = A1y[s] + ty; D1z[s] = A1z[s] + tz;
+                    const T cm = s == 1 ? inv_du : ((s >= 2) ? inv_h2 : T(0));
+                    const T cp = s == S - 2 ? -inv_du : ((s <= S - 3) ? -inv_h2 : T(0));
+                    const T c0 = s == 0 ? -inv_du : (s == S - 1 ? inv_du : T(0));
+                    const int lo = s == 0 ? 0 : s - 1, hi = s == S - 1 ? s : s + 1;
+                    D1x[s] = A1x[s] + (cm * A2x[lo] + c0 * A2x[s] + cp * A2x[hi]);
+                    D1y[s] = A1y[s] + (cm * A2y[lo] + c0 * A2y[s] + cp * A2y[hi]);
+                    D1z[s] = A1z[s] + (cm * A2z[lo] + c0 * A2z[s] + cp * A2z[hi]);
                 }
             }
             wave_lds_sync();
@@ -489,26 +479,24 @@ __global__ void __launch_bounds__(256) eval_kernel(const EvalArgs<T> a)
             for (int s = lane; s < S; s += 64) {
                 T gx = G0[s], gy = G1[s], gz = G2[s], gw = GY[s];
                 const T px = P0[s], py = P1[s], pz = P2[s], yw = YW[s];
-                if (mask & 1u) {
+                if (mask & 1u) {  // SEGW[i] = w_len / |P[i+1] - P[i]| from the forward pass
                     if (s >= 1) {
-                        T ex = px - P0[s - 1], ey = py - P1[s - 1], ez = pz - P2[s - 1];
-                        T n = mp_sqrt(ex * ex + ey * ey + ez * ez);
-                        if (n > T(0)) { T k = a.w[0] / n; gx += k * ex; gy += k * ey; gz += k * ez; }
+                        const T k = SEGW[s - 1];
+                        gx += k * (px - P0[s - 1]); gy += k * (py - P1[s - 1]); gz += k * (pz - P2[s - 1]);
                     }
                     if (s + 1 < S) {
-                        T ex = P0[s + 1] - px, ey = P1[s + 1] - py, ez = P2[s + 1] - pz;
-                        T n = mp_sqrt(ex * ex + ey * ey + ez * ez);
-                        if (n > T(0)) { T k = a.w[0] / n; gx -= k * ex; gy -= k * ey; gz -= k * ez; }
+                        const T k = SEGW[s];
+                        gx -= k * (P0[s + 1] - px); gy -= k * (P1[s + 1] - py); gz -= k * (P2[s + 1] - pz);
                     }
                 }
                 if (curv) {
-                    const T h2 = T(2) * du;
-                    if (s == 0) { gx -= D1x[0] / du; gy -= D1y[0] / du; gz -= D1z[0] / du; }
-                    if (s == 1) { gx += D1x[0] / du; gy += D1y[0] / du; gz += D1z[0] / du; }
-                    if (s == S - 2) { gx -= D1x[S - 1] / du; gy -= D1y[S - 1] / du; gz -= D1z[S - 1] / du; }
-                    if (s == S - 1) { gx += D1x[S - 1] / du; gy += D1y[S - 1] / du; gz += D1z[S - 1] / du; }
-                    if (s - 1 >= 1 && s - 1 <= S - 2) { gx += D1x[s - 1] / h2; gy += D1y[s - 1] / h2; gz += D1z[s - 1] / h2; }
-                    if (s + 1 >= 1 && s + 1 <= S - 2) { gx -= D1x[s + 1] / h2; gy -= D1y[s + 1] / h2; gz -= D1z[s + 1] / h2; }
+                    const T cm = s == 1 ? inv_du : ((s >= 2) ? inv_h2 : T(0));
+                    const T cp = s == S - 2 ? -inv_du : ((s <= S - 3) ? -inv_h2 : T(0));
+                    const T c0 = s == 0 ? -inv_du : (s == S - 1 ? inv_du : T(0));
+                    const int lo = s == 0 ? 0 : s - 1, hi = s == S - 1 ? s : s + 1;
+                    gx += cm * D1x[lo] + c0 * D1x[s] + cp * D1x[hi];
+                    gy += cm * D1y[lo] + c0 * D1y[s] + cp * D1y[hi];
+                    gz += cm * D1z[lo] + c0 * D1z[s] + cp * D1z[hi];
                 }
                 if (s == S - 1) { gx += gnx; gy += gny; gz += gnz; }
                 if (s == gn_first) { gx -= gnx; gy -= gny; gz -= gnz; }
