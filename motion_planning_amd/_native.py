@@ -15,7 +15,10 @@ import numpy as np
 from . import _abi as abi
 from .problem import PathProblem
 
-LIB_PATH = Path(__file__).resolve().parent / "libmp_hip.so"
+import os
+
+# MP_HIP_LIB lets kernel-tuning runs A/B another build of the same library
+LIB_PATH = Path(os.environ.get("MP_HIP_LIB") or (Path(__file__).resolve().parent / "libmp_hip.so"))
 _lib = None
 
 

@@ -10,6 +10,9 @@
 
 namespace mp {
 
+#ifndef MP_MIN_WAVES
+#define MP_MIN_WAVES 3
+#endif
 constexpr int kMaxCtrl = 16;
 constexpr int kNTerms = 15;
 
@@ -56,7 +59,7 @@ __host__ __device__ inline int lds_bytes_per_wave(int S, int e)
 }
 
 template <typename T, int MODEL, bool GRAD>
-__global__ void __launch_bounds__(256) eval_kernel(const EvalArgs<T> a)
+__global__ void __launch_bounds__(256, MP_MIN_WAVES) eval_kernel(const EvalArgs<T> a)
 {
     extern __shared__ __align__(16) unsigned char smem_raw[];
     const int lane = threadIdx.x & 63;
@@ -88,8 +91,9 @@ __global__ void __launch_bounds__(256) eval_kernel(const EvalArgs<T> a)
         const int t = __builtin_amdgcn_readfirstlane((int)tl);
         const DevTask<T> &tk = a.tasks[t];
         const T *x = a.X + cand * D;
-        const int nb = tk.box_count;
-        const BoxRec<T> *boxes = a.boxes + tk.box_begin;
+        const int nb = __builtin_amdgcn_readfirstlane(tk.box_count);
+        const int box_begin = __builtin_amdgcn_readfirstlane(tk.box_begin);
+        const BoxRec<T> *boxes = a.boxes + box_begin;
 
         // ---- waypoint table W[j][0..2] = position rows, W[j][3] = yaw controls ----
         {
@@ -203,7 +207,7 @@ __global__ void __launch_bounds__(256) eval_kernel(const EvalArgs<T> a)
         // ---- clearance profile d_safe ----
         int Sp = a.Sp;
         if (MODEL == 1) {
-            const BoxRec32 *boxes32 = a.boxes32 + tk.box_begin;
+            const BoxRec32 *boxes32 = a.boxes32 + box_begin;
             const float ax32 = (float)a.ax, ay32 = (float)a.ay, az32 = (float)a.az;
             for (int k0 = 0; k0 < Sp; k0 += 64) {
                 // this lane's own collision sample
@@ -404,25 +408,46 @@ __global__ void __launch_bounds__(256) eval_kernel(const EvalArgs<T> a)
 
         // ---- reductions over the wave and outputs ----
         T term[kNTerms];
-        term[0] = (mask & 1u) ? wave_sum(t_len) : T(0);
-        term[1] = ((mask & 2u) && S >= 3) ? wave_sum(t_curv) * du : T(0);
-        term[2] = ((mask & 4u) && S >= 3) ? wave_sum(t_ys) : T(0);
-        term[3] = wave_sum(t_safe);
-        term[4] = wave_sum(t_pref);
-        term[5] = wave_sum(t_reb);
-        term[6] = wave_sum(t_gc);
-        term[7] = wave_sum(t_gt);
-        term[8] = wave_sum(t_ac);
-        term[9] = wave_sum(t_acol);
-        term[10] = t_via;
-        term[11] = t_ydev;
-        term[12] = (mask & (1u << 12)) ? wave_sum(t_mono) : T(0);
-        term[13] = (mask & (1u << 13)) ? wave_sum(t_sched) : T(0);
-        term[14] = t_gn;
         T jtot = T(0);
+        if (a.terms) {
+            term[0] = (mask & 1u) ? wave_sum(t_len) : T(0);
+            term[1] = ((mask & 2u) && S >= 3) ? wave_sum(t_curv) * du : T(0);
+            term[2] = ((mask & 4u) && S >= 3) ? wave_sum(t_ys) : T(0);
+            term[3] = wave_sum(t_safe);
+            term[4] = wave_sum(t_pref);
+            term[5] = wave_sum(t_reb);
+            term[6] = wave_sum(t_gc);
+            term[7] = wave_sum(t_gt);
+            term[8] = wave_sum(t_ac);
+            term[9] = wave_sum(t_acol);
+            term[10] = t_via;
+            term[11] = t_ydev;
+            term[12] = (mask & (1u << 12)) ? wave_sum(t_mono) : T(0);
+            term[13] = (mask & (1u << 13)) ? wave_sum(t_sched) : T(0);
+            term[14] = t_gn;
 #pragma unroll
-        for (int i = 0; i < kNTerms; ++i)
-            if (mask & (1u << i)) jtot = (i == 0) ? a.w[i] * term[i] : jtot + a.w[i] * term[i];
+            for (int i = 0; i < kNTerms; ++i)
+                if (mask & (1u << i)) jtot = (i == 0) ? a.w[i] * term[i] : jtot + a.w[i] * term[i];
+        } else {
+            // cost only: weight the per-lane partial sums first, one wave reduction instead of twelve
+            T part = T(0);
+            if (mask & 1u) part += a.w[0] * t_len;
+            if ((mask & 2u) && S >= 3) part += (a.w[1] * du) * t_curv;
+            if ((mask & 4u) && S >= 3) part += a.w[2] * t_ys;
+            if (mask & (1u << 3)) part += a.w[3] * t_safe;
+            if (mask & (1u << 4)) part += a.w[4] * t_pref;
+            if (mask & (1u << 5)) part += a.w[5] * t_reb;
+            if (mask & (1u << 6)) part += a.w[6] * t_gc;
+            if (mask & (1u << 7)) part += a.w[7] * t_gt;
+            if (mask & (1u << 8)) part += a.w[8] * t_ac;
+            if (mask & (1u << 9)) part += a.w[9] * t_acol;
+            if (mask & (1u << 12)) part += a.w[12] * t_mono;
+            if (mask & (1u << 13)) part += a.w[13] * t_sched;
+            jtot = wave_sum(part);
+            if (mask & (1u << 10)) jtot += a.w[10] * t_via;
+            if (mask & (1u << 11)) jtot += a.w[11] * t_ydev;
+            if (mask & (1u << 14)) jtot += a.w[14] * t_gn;
+        }
         mc = wave_min(mc);
         if (lane == 0) {
             a.cost[cand] = jtot;

@@ -61,7 +61,7 @@ def test_fp64_matches_oracle_and_golden(case, native, oracle_lib):
     assert terr.max() < 1e-9, terr.max(axis=0)
     # cost-only launch (no gradient kernel variant) returns the same numbers
     out2 = ctx.eval(X, want_grad=False, want_terms=False)
-    np.testing.assert_array_equal(out2["cost"], out["cost"])
+    np.testing.assert_allclose(out2["cost"], out["cost"], rtol=1e-12)   # single weighted reduction vs per-term sums
     np.testing.assert_array_equal(out2["flags"], out["flags"])
     ctx.close()
 
@@ -122,7 +122,7 @@ def test_empty_and_ragged_inputs(native, oracle_lib):
     np.testing.assert_array_equal(np.isnan(out["cost"]), np.isnan(ref["cost"]))
     ok = ~np.isnan(ref["terms"])
     np.testing.assert_array_equal(np.isnan(out["terms"]), ~ok)
-    np.testing.assert_allclose(out["terms"][ok], ref["terms"][ok], rtol=1e-9)
+    np.testing.assert_allclose(out["terms"][ok], ref["terms"][ok], rtol=1e-9, atol=1e-18)  # x0 is a straight line: curvature is rounding noise
     ctx.close()
 
 
