@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <array>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -35,7 +36,8 @@ struct mp_ctx {
     size_t max_lds = 65536;
 
     // scene
-    DevBuf boxes, boxes32;
+    DevBuf boxes, boxes32, groups;
+    std::vector<double> h_boxes;  // host copy of the scene (n x 6) for the per-task bound tables
     float scene_radius = 0.f;
     int n_boxes = 0;
     bool have_scene = false;
@@ -201,15 +203,15 @@ template <typename T> int upload_scene(mp_ctx *ctx, int n, const double *cx, con
     }
     int rc = upload(ctx, ctx->boxes, rec.data(), (size_t)n * sizeof(mp::BoxRec<T>));
     if (rc) return rc;
-    // fp32 copy for the conservative bound pass + the scene radius its slack is scaled with
-    std::vector<mp::BoxRec32> rec32((size_t)std::max(n, 1));
+    // host copy + scene radius (scales the slack of the fp32 bound pass); the fp32 tables are built per task
+    ctx->h_boxes.resize((size_t)n * 6);
     double radius = 0.0;
     for (int i = 0; i < n; ++i) {
-        rec32[i] = mp::BoxRec32{(float)cx[i], (float)cy[i], (float)cz[i], (float)hx[i], (float)hy[i], (float)hz[i], 0.f, 0.f};
+        double *r = &ctx->h_boxes[(size_t)i * 6];
+        r[0] = cx[i]; r[1] = cy[i]; r[2] = cz[i]; r[3] = hx[i]; r[4] = hy[i]; r[5] = hz[i];
         radius = std::max({radius, std::fabs(cx[i]) + hx[i], std::fabs(cy[i]) + hy[i], std::fabs(cz[i]) + hz[i]});
     }
     ctx->scene_radius = (float)radius;
-    if ((rc = upload(ctx, ctx->boxes32, rec32.data(), (size_t)n * sizeof(mp::BoxRec32)))) return rc;
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));  // rec is a local
     return MP_OK;
 }
@@ -238,6 +240,83 @@ template <typename T> int upload_problem(mp_ctx *ctx, const mp_task *tasks)
         dt[i].yaw_inc = tasks[i].yaw_increasing;
         dt[i].box_begin = tasks[i].box_begin;
         dt[i].box_count = tasks[i].box_count;
+    }
+    // Bound-pass tables: per distinct box range, the boxes sorted along a Morton curve (fp32 records,
+    // pad0 = index relative to the range) and the AABBs of groups of kGroup consecutive boxes.
+    {
+        constexpr int kGroup = 16, kGroupMin = 128;
+        std::vector<mp::BoxRec32> sb, gr;
+        std::vector<std::array<int, 5>> done;  // begin, count, sbox_begin, group_begin, group_count
+        auto as_float = [](int v) { float f; std::memcpy(&f, &v, 4); return f; };
+        for (int i = 0; i < ctx->n_tasks; ++i) {
+            const int b0 = tasks[i].box_begin, cnt = tasks[i].box_count;
+            const std::array<int, 5> *hit = nullptr;
+            for (const auto &d : done)
+                if (d[0] == b0 && d[1] == cnt) { hit = &d; break; }
+            if (!hit) {
+                std::vector<int> order(cnt);
+                for (int k = 0; k < cnt; ++k) order[k] = k;
+                if (cnt >= kGroupMin) {
+                    double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
+                    for (int k = 0; k < cnt; ++k)
+                        for (int a = 0; a < 3; ++a) {
+                            lo[a] = std::min(lo[a], ctx->h_boxes[(size_t)(b0 + k) * 6 + a]);
+                            hi[a] = std::max(hi[a], ctx->h_boxes[(size_t)(b0 + k) * 6 + a]);
+                        }
+                    std::vector<unsigned long long> code(cnt);
+                    for (int k = 0; k < cnt; ++k) {
+                        unsigned long long c = 0;
+                        unsigned q[3];
+                        for (int a = 0; a < 3; ++a) {
+                            double t = hi[a] > lo[a] ? (ctx->h_boxes[(size_t)(b0 + k) * 6 + a] - lo[a]) / (hi[a] - lo[a]) : 0.0;
+                            q[a] = (unsigned)std::min(1023.0, std::max(0.0, t * 1024.0));
+                        }
+                        for (int bit = 9; bit >= 0; --bit)
+                            for (int a = 0; a < 3; ++a) c = (c << 1) | ((q[a] >> bit) & 1u);
+                        code[k] = c;
+                    }
+                    std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return code[x] < code[y]; });
+                }
+                const int sb0 = (int)sb.size(), g0 = (int)gr.size();
+                const int gsz = cnt >= kGroupMin ? kGroup : std::max(cnt, 1);
+                for (int k = 0; k < cnt; ++k) {
+                    const double *r = &ctx->h_boxes[(size_t)(b0 + order[k]) * 6];
+                    sb.push_back(mp::BoxRec32{(float)r[0], (float)r[1], (float)r[2], (float)r[3], (float)r[4], (float)r[5],
+                                              as_float(order[k]), 0.f});
+                }
+                for (int k = 0; k < cnt; k += gsz) {
+                    const int m = std::min(gsz, cnt - k);
+                    float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+                    for (int q = 0; q < m; ++q) {
+                        const mp::BoxRec32 &r = sb[(size_t)sb0 + k + q];
+                        const float c[3] = {r.cx, r.cy, r.cz}, h[3] = {r.hx, r.hy, r.hz};
+                        for (int a = 0; a < 3; ++a) {
+                            lo[a] = std::min(lo[a], std::nextafter(c[a] - h[a], -INFINITY));
+                            hi[a] = std::max(hi[a], std::nextafter(c[a] + h[a], INFINITY));
+                        }
+                    }
+                    mp::BoxRec32 g{};
+                    float *gc = &g.cx, *gh = &g.hx;
+                    for (int a = 0; a < 3; ++a) {
+                        gc[a] = 0.5f * (lo[a] + hi[a]);
+                        // half extent rounded up so that [c-h, c+h] contains [lo, hi] despite the rounding of c
+                        gh[a] = std::nextafter(std::max(hi[a] - gc[a], gc[a] - lo[a]), INFINITY);
+                    }
+                    g.pad0 = as_float(k);   // first sorted index, relative to sbox_begin
+                    g.pad1 = as_float(m);
+                    gr.push_back(g);
+                }
+                done.push_back({b0, cnt, sb0, g0, (int)gr.size() - g0});
+                hit = &done.back();
+            }
+            dt[i].sbox_begin = (*hit)[2];
+            dt[i].group_begin = (*hit)[3];
+            dt[i].group_count = (*hit)[4];
+            dt[i].pad = 0;
+        }
+        if ((rc = upload(ctx, ctx->boxes32, sb.data(), sb.size() * sizeof(mp::BoxRec32)))) return rc;
+        if ((rc = upload(ctx, ctx->groups, gr.data(), gr.size() * sizeof(mp::BoxRec32)))) return rc;
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     }
     if ((rc = upload(ctx, ctx->d_tasks, dt.data(), dt.size() * sizeof(mp::DevTask<T>)))) return rc;
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));  // locals go out of scope
@@ -275,7 +354,8 @@ int launch_eval(mp_ctx *ctx, long long n, const void *X, const int32_t *task_of,
     a.idx_safe = (const int *)ctx->d_idx.p; a.amask = (const uint8_t *)ctx->d_mask.p;
     a.M = (const T *)ctx->d_M.p; a.My = (const T *)ctx->d_My.p; a.tsched = (const T *)ctx->d_tsched.p;
     a.tasks = (const mp::DevTask<T> *)ctx->d_tasks.p; a.boxes = (const mp::BoxRec<T> *)ctx->boxes.p;
-    a.boxes32 = (const mp::BoxRec32 *)ctx->boxes32.p; a.scene_radius = ctx->scene_radius;
+    a.boxes32 = (const mp::BoxRec32 *)ctx->boxes32.p; a.groups = (const mp::BoxRec32 *)ctx->groups.p;
+    a.scene_radius = ctx->scene_radius;
     a.X = (const T *)X; a.task_of = task_of; a.cpt = ctx->cands_per_task; a.n = n;
     a.cost = (T *)cost; a.terms = (T *)terms; a.grad = (T *)grad; a.minc = (T *)minc; a.dist = (T *)dist;
     a.flags = flags;
@@ -351,7 +431,7 @@ int mp_destroy(mp_ctx *ctx)
     if (!ctx) return MP_OK;
     hipSetDevice(ctx->device);
     hipStreamSynchronize(ctx->stream);
-    DevBuf *bufs[] = {&ctx->boxes, &ctx->boxes32, &ctx->d_idx, &ctx->d_mask, &ctx->d_M, &ctx->d_My, &ctx->d_tsched, &ctx->d_tasks,
+    DevBuf *bufs[] = {&ctx->boxes, &ctx->boxes32, &ctx->groups, &ctx->d_idx, &ctx->d_mask, &ctx->d_M, &ctx->d_My, &ctx->d_tsched, &ctx->d_tasks,
                       &ctx->s_X, &ctx->s_taskof, &ctx->s_cost, &ctx->s_terms, &ctx->s_grad, &ctx->s_minc,
                       &ctx->s_flags, &ctx->s_dist, &ctx->s_aux0, &ctx->s_aux1};
     for (DevBuf *b : bufs)

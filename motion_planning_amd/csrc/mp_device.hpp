@@ -273,7 +273,7 @@ __device__ __forceinline__ BoxRec32 load_box32_uniform(const BoxRec32 *boxes, in
     CPtr p = (CPtr)(unsigned long long)(boxes + i);
     BoxRec32 r;
     r.cx = p[0]; r.cy = p[1]; r.cz = p[2]; r.hx = p[3]; r.hy = p[4]; r.hz = p[5];
-    r.pad0 = 0.f; r.pad1 = 0.f;
+    r.pad0 = p[6]; r.pad1 = p[7];
     return r;
 }
 

@@ -21,6 +21,10 @@ template <typename T> struct DevTask {
     T yaw_ctrl[kMaxCtrl];
     T normal[3];
     int has_normal, yaw_inc, box_begin, box_count;
+    int sbox_begin;    // first record of this task's spatially sorted fp32 table (sboxes32)
+    int group_begin;   // first record of this task's group table
+    int group_count;   // groups of kGroupSize consecutive sorted boxes (1 group: no group test)
+    int pad;
 };
 
 template <typename T> struct EvalArgs {
@@ -37,7 +41,8 @@ template <typename T> struct EvalArgs {
     const T *tsched;
     const DevTask<T> *tasks;
     const BoxRec<T> *boxes;
-    const BoxRec32 *boxes32;  // fp32 copy of the box table for the bound pass
+    const BoxRec32 *boxes32;  // fp32 bound-pass table, sorted along a Morton curve per task; pad0 = original index
+    const BoxRec32 *groups;   // AABB of each group of consecutive sorted boxes; pad0/pad1 = first / count
     float scene_radius;       // max |centre| + half extent over the scene (slack of the bound)
     const T *X;
     const int *task_of;
@@ -207,7 +212,9 @@ __global__ void __launch_bounds__(256, MP_MIN_WAVES) eval_kernel(const EvalArgs<
         // ---- clearance profile d_safe ----
         int Sp = a.Sp;
         if (MODEL == 1) {
-            const BoxRec32 *boxes32 = a.boxes32 + box_begin;
+            const BoxRec32 *boxes32 = a.boxes32 + __builtin_amdgcn_readfirstlane(tk.sbox_begin);
+            const BoxRec32 *groups = a.groups + __builtin_amdgcn_readfirstlane(tk.group_begin);
+            const int ngroups = __builtin_amdgcn_readfirstlane(tk.group_count);
             const float ax32 = (float)a.ax, ay32 = (float)a.ay, az32 = (float)a.az;
             for (int k0 = 0; k0 < Sp; k0 += 64) {
                 // this lane's own collision sample
@@ -264,23 +271,33 @@ __global__ void __launch_bounds__(256, MP_MIN_WAVES) eval_kernel(const EvalArgs<
                     if (valid) U32 = (float)key_to_sep2<T>(MINKEY[k]) * (1.0f + 4e-6f);
                 };
 
-                BoxRec32 nxt = load_box32_uniform(boxes32, 0);
-                for (int b = 0; b < nb; ++b) {
-                    const BoxRec32 bx = nxt;
-                    nxt = load_box32_uniform(boxes32, b + 1 < nb ? b + 1 : b);
-                    const float lb2 = aabb_lb2(px32, py32, pz32, exs, eys, ezs, bx);
-                    const bool need = valid && (lb2 <= U32);
-                    const unsigned long long m = __builtin_amdgcn_ballot_w64(need);
-                    if (m) {
-                        if (need) {
-                            const int pos = __builtin_amdgcn_mbcnt_hi((unsigned int)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)m, 0u));
-                            QUEUE[(qhead + qcount + pos) & 127] = ((unsigned int)lane << 24) | (unsigned int)b;
-                        }
-                        qcount += __builtin_popcountll(m);
-                        if (qcount >= 64) {
-                            drain(64);
-                            qhead = (qhead + 64) & 127;
-                            qcount -= 64;
+                // Bound pass over the task's boxes in sorted order.  With several groups a whole group
+                // is skipped when no lane of the wave can be closer to its AABB than its current minimum.
+                for (int g = 0; g < ngroups; ++g) {
+                    const BoxRec32 grp = load_box32_uniform(groups, g);
+                    const int gfirst = __float_as_int(grp.pad0), gcnt = __float_as_int(grp.pad1);
+                    if (ngroups > 1) {
+                        const float lbg = aabb_lb2(px32, py32, pz32, exs, eys, ezs, grp);
+                        if (!__builtin_amdgcn_ballot_w64(valid && (lbg <= U32))) continue;
+                    }
+                    BoxRec32 nxt = load_box32_uniform(boxes32, gfirst);
+                    for (int i = 0; i < gcnt; ++i) {
+                        const BoxRec32 bx = nxt;
+                        nxt = load_box32_uniform(boxes32, gfirst + (i + 1 < gcnt ? i + 1 : i));
+                        const float lb2 = aabb_lb2(px32, py32, pz32, exs, eys, ezs, bx);
+                        const bool need = valid && (lb2 <= U32);
+                        const unsigned long long m = __builtin_amdgcn_ballot_w64(need);
+                        if (m) {
+                            if (need) {
+                                const int pos = __builtin_amdgcn_mbcnt_hi((unsigned int)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)m, 0u));
+                                QUEUE[(qhead + qcount + pos) & 127] = ((unsigned int)lane << 24) | (unsigned int)__float_as_int(bx.pad0);
+                            }
+                            qcount += __builtin_popcountll(m);
+                            if (qcount >= 64) {
+                                drain(64);
+                                qhead = (qhead + 64) & 127;
+                                qcount -= 64;
+                            }
                         }
                     }
                 }
