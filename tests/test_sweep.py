@@ -1,0 +1,49 @@
+"""Sweep bookkeeping (counterpart of example/benchmark_planners.py) on CPU with the oracle evaluator."""
+import numpy as np
+import pytest
+
+from motion_planning_amd import sweep
+from motion_planning_amd.scenarios import scenario_from_resolved
+from tests import helpers as H
+
+
+def test_random_search_draws_are_reproducible_and_on_grid():
+    for method, n_rng in (("Powell", 9), ("CEM", 12), ("CEM-POWELL", 15)):
+        a = sweep.sample_strategy_config(method, np.random.default_rng(7))
+        b = sweep.sample_strategy_config(method, np.random.default_rng(7))
+        assert a == b
+        cfg, opts = a
+        assert cfg["w_len"] in (3.5, 5.0, 6.0) and cfg["init_offset_scale"] in (0.5, 0.7, 1.0)
+        assert cfg["n_samples_curve"] == 101 and cfg["w_safe"] in (260.0, 380.0, 520.0)
+    _, opts = sweep.sample_strategy_config("cem", np.random.default_rng(1))
+    assert set(opts) == {"population_size", "elite_frac", "max_iter", "alpha", "min_sigma", "tol", "seed"}
+    _, opts = sweep.sample_strategy_config("hybrid", np.random.default_rng(1))
+    assert set(opts) == {"cem", "powell"} and opts["cem"]["max_iter"] in (45, 60, 90)
+    with pytest.raises(ValueError, match="Unsupported method"):
+        sweep.sample_strategy_config("SGD", np.random.default_rng(0))
+    # the draw sequence is the reference's: first draw of default_rng(7) picks init_offset_scale
+    rng = np.random.default_rng(7)
+    first = float(rng.choice([0.5, 0.7, 1.0]))
+    assert sweep.sample_strategy_config("Powell", np.random.default_rng(7))[0]["init_offset_scale"] == first
+
+
+def test_score_and_seeds():
+    assert sweep.scenario_score({"fun": 2.0, "min_clearance": 0.1, "success": True}, 10.0) == pytest.approx(3.5)
+    assert sweep.scenario_score({"fun": 2.0, "min_clearance": -0.01, "success": False}, 0.0) == pytest.approx(2.0 + 5.0 + 10000.0)
+    assert [sweep.method_seed(7, m) for m in ("Powell", "CEM", "CEM-POWELL")] == [7, 10007, 20007]
+
+
+def test_small_sweep_end_to_end(oracle_lib):
+    table = {k: v for k, v in H.load_scenarios().items() if k.startswith("step_0")}
+    names = sorted(table)[:2]
+    out = sweep.run_sweep(lambda n: scenario_from_resolved(table[n]), names, methods=("Powell",), trials=1, seed=7, log=None,
+                          evaluator_factory=oracle_lib.OracleEvaluator)
+    assert out["train_scenarios"] == names[:1] and out["test_scenarios"] == names
+    b = out["benchmark"]["Powell"]
+    assert set(b["aggregate"]["metrics"]) == set(sweep.AGGREGATE_KEYS)
+    assert len(b["per_scenario"]) == 2 and all(r["success"] in (True, False) for r in b["per_scenario"])
+    assert b["aggregate"]["metrics"]["path_efficiency"]["min"] >= 1.0 - 1e-9
+    with pytest.raises(ValueError, match="No scenarios"):
+        sweep.run_sweep(lambda n: None, [], log=None)
+    with pytest.raises(ValueError, match="Unsupported method"):
+        sweep.run_sweep(lambda n: None, names, methods=("Adam",), log=None)
