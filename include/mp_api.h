@@ -212,6 +212,34 @@ int mp_box_sdf(mp_ctx *ctx, int64_t n, const void *pos, const void *yaw_deg,
                const double size[3], int32_t box_begin, int32_t box_count, void *out,
                int mem);
 
+/* ---- batched cross-entropy method, resident on the GPU --------------------------------
+ * Replaces _cem_optimize (geom/spline_opt.py:222-277) and the objective_batch round trip per
+ * generation (:301-304) for MANY independent instances (scenarios x restarts) in lock-step:
+ * sampling, evaluation, elite refit and the stopping rule all run on the device; the host only
+ * polls how many instances are still running.  Same update equations and stopping rule as the
+ * reference; option names and defaults as in spline_opt.py:289-297. */
+typedef struct mp_cem_options {
+    int32_t population_size; /* 64 */
+    int32_t max_iter;        /* 90 */
+    double elite_frac;       /* 0.2  -> elite_count = max(2, ceil(pop * elite_frac)) */
+    double tol;              /* 1e-3 */
+    double alpha;            /* 0.7 */
+    double min_sigma;        /* 1e-3 */
+    uint64_t seed;           /* device Philox stream (ignored when `noise` is given) */
+} mp_cem_options;
+
+/*   task_of_inst [n_inst] or NULL  task of each instance (NULL: instance i -> task i / insts_per_task,
+ *                                  insts_per_task = ceil(n_inst / n_tasks))
+ *   x0, sigma0   [n_inst x D]      start mean / spread of every instance        (context dtype)
+ *   noise        NULL, or [max_iter x n_inst x pop x D] standard-normal draws: generation g of instance i
+ *                uses noise[g][i] instead of the device generator (seed-parity runs feed NumPy's stream)
+ *   best_x [n_inst x D], best_val [n_inst], nit [n_inst]            results (best_x/best_val required)
+ *   best_min_clear [n_inst], best_flags [n_inst]                    of the best candidate (or NULL)
+ * All pointers are host (MP_MEM_HOST) or device (MP_MEM_DEVICE) pointers; synchronous on return. */
+int mp_cem_solve(mp_ctx *ctx, int64_t n_inst, const int32_t *task_of_inst, const void *x0, const void *sigma0,
+                 const mp_cem_options *opt, const void *noise, void *best_x, void *best_val, int32_t *nit,
+                 void *best_min_clear, uint8_t *best_flags, int mem);
+
 #ifdef __cplusplus
 }
 #endif

@@ -98,3 +98,15 @@ class MpTask(C.Structure):
         ("box_begin", C.c_int32),
         ("box_count", C.c_int32),
     ]
+
+
+class MpCemOptions(C.Structure):
+    _fields_ = [
+        ("population_size", C.c_int32),
+        ("max_iter", C.c_int32),
+        ("elite_frac", C.c_double),
+        ("tol", C.c_double),
+        ("alpha", C.c_double),
+        ("min_sigma", C.c_double),
+        ("seed", C.c_uint64),
+    ]

@@ -64,9 +64,10 @@ def load():
     lib.mp_eval.argtypes = [vp, i64, vp, vp, vp, vp, vp, vp, vp, vp, C.c_int]
     lib.mp_point_sdf.argtypes = [vp, i64, vp, C.c_double, i32, i32, vp, C.c_int]
     lib.mp_box_sdf.argtypes = [vp, i64, vp, vp, vp, i32, i32, vp, C.c_int]
+    lib.mp_cem_solve.argtypes = [vp, i64, vp, vp, vp, C.POINTER(abi.MpCemOptions), vp, vp, vp, vp, vp, vp, C.c_int]
     for name in ("mp_create", "mp_destroy", "mp_set_stream", "mp_synchronize", "mp_timer_start", "mp_timer_stop",
                  "mp_set_scene", "mp_set_problem", "mp_build_basis", "mp_get_basis", "mp_set_cands_per_task",
-                 "mp_eval", "mp_point_sdf", "mp_box_sdf"):
+                 "mp_eval", "mp_point_sdf", "mp_box_sdf", "mp_cem_solve"):
         getattr(lib, name).restype = C.c_int
     if lib.mp_api_version() != abi.MP_API_VERSION:
         raise ImportError("libmp_hip.so was built from a different mp_api.h version")
@@ -222,3 +223,31 @@ class Context:
         self._check(self.lib.mp_box_sdf(self._h, pos.shape[0], _p(pos), _p(yaw), C.cast(sz, C.c_void_p), box_begin, cnt,
                                         _p(out), abi.MP_MEM_HOST))
         return out
+
+    # -- device-resident CEM over many instances --
+    def cem_solve(self, x0: np.ndarray, sigma0: np.ndarray, task_of: Optional[np.ndarray] = None, population_size: int = 64,
+                  elite_frac: float = 0.2, max_iter: int = 90, tol: float = 1e-3, alpha: float = 0.7, min_sigma: float = 1e-3,
+                  seed: Optional[int] = None, noise: Optional[np.ndarray] = None):
+        """Batched _cem_optimize (geom/spline_opt.py:222-277): one instance per row of x0."""
+        p = self.problem
+        if p is None:
+            raise RuntimeError("set_problem first")
+        dt = self.np_dtype
+        x0 = np.ascontiguousarray(x0, dtype=dt).reshape(-1, p.dim)
+        n = x0.shape[0]
+        sigma0 = np.ascontiguousarray(np.broadcast_to(np.asarray(sigma0, dtype=dt), x0.shape))
+        opt = abi.MpCemOptions(int(population_size), int(max_iter), float(elite_frac), float(tol), float(alpha),
+                               float(min_sigma), int(seed if seed is not None else np.random.SeedSequence().entropy & (2**63 - 1)))
+        if noise is not None:
+            noise = np.ascontiguousarray(noise, dtype=dt)
+            if noise.shape != (max_iter, n, population_size, p.dim):
+                raise ValueError("noise must have shape (max_iter, n_inst, population_size, D)")
+        tof = None if task_of is None else np.ascontiguousarray(task_of, dtype=np.int32)
+        best_x = np.empty((n, p.dim), dtype=dt)
+        best_val = np.empty(n, dtype=dt)
+        nit = np.empty(n, dtype=np.int32)
+        minc = np.empty(n, dtype=dt)
+        flags = np.empty(n, dtype=np.uint8)
+        self._check(self.lib.mp_cem_solve(self._h, n, _p(tof), _p(x0), _p(sigma0), C.byref(opt), _p(noise), _p(best_x),
+                                          _p(best_val), _p(nit), _p(minc), _p(flags), abi.MP_MEM_HOST))
+        return {"x": best_x, "fun": best_val, "nit": nit, "min_clear": minc, "flags": flags}

@@ -129,3 +129,46 @@ def best_feasible(cost: torch.Tensor, flags: torch.Tensor) -> Tuple[int, float, 
         return i, float(cost[i]), True
     i = int(torch.argmin(cost))
     return i, float(cost[i]), False
+
+
+def solve_scenarios_cem(problems: Sequence[PathProblem], restarts: int = 32, device: int = 0, dtype=np.float64,
+                        restart_seed: int = 0, **cem_options) -> Dict[str, np.ndarray]:
+    """Scenario-parallel planning (BASELINE config 5): every scenario gets ``restarts`` independent CEM
+    solves started from x0 + sigma0 * eps (restart 0 from x0 itself), all instances advance in lock-step
+    on the GPU, and the best restart of each scenario is returned.
+
+    "solved" follows SURVEY.md §8d: the best candidate is feasible (min clearance >= required)."""
+    from . import _native
+
+    p0 = problems[0]
+    n_s, D = len(problems), p0.dim
+    rng = np.random.default_rng(restart_seed)
+    x0 = np.empty((n_s, restarts, D))
+    s0 = np.empty((n_s, restarts, D))
+    for i, p in enumerate(problems):
+        eps = rng.normal(size=(restarts, D))
+        eps[0] = 0.0
+        x0[i] = p.x0[None, :] + eps * p.sigma0[None, :]
+        s0[i] = p.sigma0[None, :]
+    ctx = _native.Context(device, dtype)
+    try:
+        ctx.set_problem(list(problems))
+        task_of = np.repeat(np.arange(n_s, dtype=np.int32), restarts)
+        res = ctx.cem_solve(x0.reshape(-1, D), s0.reshape(-1, D), task_of=task_of, **cem_options)
+    finally:
+        ctx.close()
+    fun = res["fun"].astype(float).reshape(n_s, restarts)
+    flags = res["flags"].reshape(n_s, restarts)
+    feas = (flags & abi.MP_FLAG_FEASIBLE) != 0
+    masked = np.where(feas, fun, np.inf)
+    pick = np.where(feas.any(axis=1), np.argmin(masked, axis=1), np.argmin(fun, axis=1))
+    rows = np.arange(n_s)
+    return {
+        "x": res["x"].reshape(n_s, restarts, D)[rows, pick],
+        "fun": fun[rows, pick],
+        "min_clear": res["min_clear"].astype(float).reshape(n_s, restarts)[rows, pick],
+        "solved": feas[rows, pick],
+        "restart": pick,
+        "nit": res["nit"].reshape(n_s, restarts),
+        "all_fun": fun,
+    }

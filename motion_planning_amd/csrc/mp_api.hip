@@ -52,6 +52,10 @@ struct mp_ctx {
 
     // staging for MP_MEM_HOST calls
     DevBuf s_X, s_taskof, s_cost, s_terms, s_grad, s_minc, s_flags, s_dist, s_aux0, s_aux1;
+
+    // device-resident CEM
+    DevBuf c_X, c_vals, c_minc, c_flags, c_mu, c_sigma, c_bestx, c_bestval, c_prev, c_bminc, c_bflags, c_done, c_nit,
+        c_active, c_task, c_x0, c_s0, c_noise;
 };
 
 namespace {
@@ -337,7 +341,8 @@ int launch_eval_k(mp_ctx *ctx, const mp::EvalArgs<T> &args, int wpb, int blocks,
 
 template <typename T>
 int launch_eval(mp_ctx *ctx, long long n, const void *X, const int32_t *task_of, void *cost, void *terms, void *grad,
-                void *minc, uint8_t *flags, void *dist)
+                void *minc, uint8_t *flags, void *dist, int group_size = 0, const int *group_task = nullptr,
+                const uint8_t *group_done = nullptr)
 {
     const mp_config &c = ctx->cfg;
     mp::EvalArgs<T> a{};
@@ -357,6 +362,7 @@ int launch_eval(mp_ctx *ctx, long long n, const void *X, const int32_t *task_of,
     a.boxes32 = (const mp::BoxRec32 *)ctx->boxes32.p; a.groups = (const mp::BoxRec32 *)ctx->groups.p;
     a.scene_radius = ctx->scene_radius;
     a.X = (const T *)X; a.task_of = task_of; a.cpt = ctx->cands_per_task; a.n = n;
+    a.group_size = group_size; a.group_task = group_task; a.group_done = group_done;
     a.cost = (T *)cost; a.terms = (T *)terms; a.grad = (T *)grad; a.minc = (T *)minc; a.dist = (T *)dist;
     a.flags = flags;
 
@@ -375,6 +381,70 @@ int launch_eval(mp_ctx *ctx, long long n, const void *X, const int32_t *task_of,
                  : launch_eval_k<T, 1, false>(ctx, a, wpb, blocks, lds_bytes);
     return g ? launch_eval_k<T, 0, true>(ctx, a, wpb, blocks, lds_bytes)
              : launch_eval_k<T, 0, false>(ctx, a, wpb, blocks, lds_bytes);
+}
+
+template <typename T>
+int cem_solve(mp_ctx *ctx, long long n_inst, const int32_t *d_task, const T *d_x0, const T *d_s0, const mp_cem_options &o,
+              const T *d_noise, T *best_x, T *best_val, int32_t *nit, T *best_minc, uint8_t *best_flags, int mem)
+{
+    const mp_config &c = ctx->cfg;
+    const int D = 3 * c.n_free + c.n_yaw_free, pop = o.population_size;
+    const int n_elite = std::max(2, (int)std::ceil(pop * o.elite_frac));
+    const size_t nd = (size_t)n_inst * D, np_ = (size_t)n_inst * pop;
+    int rc;
+    if ((rc = reserve(ctx, ctx->c_X, np_ * D * sizeof(T)))) return rc;
+    if ((rc = reserve(ctx, ctx->c_vals, np_ * sizeof(T)))) return rc;
+    if ((rc = reserve(ctx, ctx->c_minc, np_ * sizeof(T)))) return rc;
+    if ((rc = reserve(ctx, ctx->c_flags, np_))) return rc;
+    if ((rc = reserve(ctx, ctx->c_mu, nd * sizeof(T)))) return rc;
+    if ((rc = reserve(ctx, ctx->c_sigma, nd * sizeof(T)))) return rc;
+    if ((rc = reserve(ctx, ctx->c_bestx, nd * sizeof(T)))) return rc;
+    if ((rc = reserve(ctx, ctx->c_bestval, (size_t)n_inst * sizeof(T)))) return rc;
+    if ((rc = reserve(ctx, ctx->c_prev, (size_t)n_inst * sizeof(T)))) return rc;
+    if ((rc = reserve(ctx, ctx->c_bminc, (size_t)n_inst * sizeof(T)))) return rc;
+    if ((rc = reserve(ctx, ctx->c_bflags, (size_t)n_inst))) return rc;
+    if ((rc = reserve(ctx, ctx->c_done, (size_t)n_inst))) return rc;
+    if ((rc = reserve(ctx, ctx->c_nit, (size_t)n_inst * sizeof(int)))) return rc;
+    if ((rc = reserve(ctx, ctx->c_active, 256))) return rc;
+    mp::CemState<T> st{(T *)ctx->c_mu.p, (T *)ctx->c_sigma.p, (T *)ctx->c_bestx.p, (T *)ctx->c_bestval.p,
+                       (T *)ctx->c_prev.p, (T *)ctx->c_bminc.p, (uint8_t *)ctx->c_bflags.p, (uint8_t *)ctx->c_done.p,
+                       (int *)ctx->c_nit.p, (int *)ctx->c_active.p};
+    const int eb = (int)std::min<long long>(((long long)nd + 255) / 256, (long long)ctx->num_cu * 8);
+    hipLaunchKernelGGL(mp::cem_init_kernel<T>, dim3(std::max(eb, 1)), dim3(256), 0, ctx->stream, n_inst, D, st, d_x0, d_s0,
+                       (T)o.min_sigma);
+    HIP_TRY(ctx, hipGetLastError());
+    const int sb = (int)std::min<long long>(((long long)np_ * D + 255) / 256, (long long)ctx->num_cu * 16);
+    const int wpb = 4;
+    const int ub = (int)std::min<long long>((n_inst + wpb - 1) / wpb, (long long)ctx->num_cu * 16);
+    const size_t ulds = (size_t)wpb * pop * sizeof(T);
+    for (int gen = 0; gen < o.max_iter; ++gen) {
+        const T *noise_g = d_noise ? d_noise + (size_t)gen * np_ * D : nullptr;
+        hipLaunchKernelGGL(mp::cem_sample_kernel<T>, dim3(sb), dim3(256), 0, ctx->stream, n_inst, pop, D, st, noise_g,
+                           (unsigned long long)o.seed, gen, (T *)ctx->c_X.p);
+        HIP_TRY(ctx, hipGetLastError());
+        if ((rc = launch_eval<T>(ctx, (long long)np_, ctx->c_X.p, nullptr, ctx->c_vals.p, nullptr, nullptr, ctx->c_minc.p,
+                                 (uint8_t *)ctx->c_flags.p, nullptr, pop, d_task, (const uint8_t *)ctx->c_done.p)))
+            return rc;
+        HIP_TRY(ctx, hipMemsetAsync(ctx->c_active.p, 0, sizeof(int), ctx->stream));
+        hipLaunchKernelGGL(mp::cem_update_kernel<T>, dim3(ub), dim3(64 * wpb), ulds, ctx->stream, n_inst, pop, D, n_elite,
+                           (T)o.alpha, (T)o.min_sigma, (T)o.tol, st, (const T *)ctx->c_X.p, (const T *)ctx->c_vals.p,
+                           (const T *)ctx->c_minc.p, (const uint8_t *)ctx->c_flags.p);
+        HIP_TRY(ctx, hipGetLastError());
+        if ((gen & 3) == 3 || gen + 1 == o.max_iter) {  // poll every 4 generations
+            int active = 0;
+            HIP_TRY(ctx, hipMemcpyAsync(&active, ctx->c_active.p, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+            HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+            if (active == 0) break;
+        }
+    }
+    const hipMemcpyKind kind = mem == MP_MEM_HOST ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice;
+    HIP_TRY(ctx, hipMemcpyAsync(best_x, ctx->c_bestx.p, nd * sizeof(T), kind, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(best_val, ctx->c_bestval.p, (size_t)n_inst * sizeof(T), kind, ctx->stream));
+    if (nit) HIP_TRY(ctx, hipMemcpyAsync(nit, ctx->c_nit.p, (size_t)n_inst * sizeof(int), kind, ctx->stream));
+    if (best_minc) HIP_TRY(ctx, hipMemcpyAsync(best_minc, ctx->c_bminc.p, (size_t)n_inst * sizeof(T), kind, ctx->stream));
+    if (best_flags) HIP_TRY(ctx, hipMemcpyAsync(best_flags, ctx->c_bflags.p, (size_t)n_inst, kind, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return MP_OK;
 }
 
 int check_ctx(mp_ctx *ctx)
@@ -433,7 +503,10 @@ int mp_destroy(mp_ctx *ctx)
     hipStreamSynchronize(ctx->stream);
     DevBuf *bufs[] = {&ctx->boxes, &ctx->boxes32, &ctx->groups, &ctx->d_idx, &ctx->d_mask, &ctx->d_M, &ctx->d_My, &ctx->d_tsched, &ctx->d_tasks,
                       &ctx->s_X, &ctx->s_taskof, &ctx->s_cost, &ctx->s_terms, &ctx->s_grad, &ctx->s_minc,
-                      &ctx->s_flags, &ctx->s_dist, &ctx->s_aux0, &ctx->s_aux1};
+                      &ctx->s_flags, &ctx->s_dist, &ctx->s_aux0, &ctx->s_aux1, &ctx->c_X, &ctx->c_vals, &ctx->c_minc,
+                      &ctx->c_flags, &ctx->c_mu, &ctx->c_sigma, &ctx->c_bestx, &ctx->c_bestval, &ctx->c_prev, &ctx->c_bminc,
+                      &ctx->c_bflags, &ctx->c_done, &ctx->c_nit, &ctx->c_active, &ctx->c_task, &ctx->c_x0, &ctx->c_s0,
+                      &ctx->c_noise};
     for (DevBuf *b : bufs)
         if (b->p) hipFree(b->p);
     if (ctx->ev0) hipEventDestroy(ctx->ev0);
@@ -714,6 +787,53 @@ int mp_box_sdf(mp_ctx *ctx, int64_t n, const void *pos, const void *yaw_deg, con
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     }
     return MP_OK;
+}
+
+int mp_cem_solve(mp_ctx *ctx, int64_t n_inst, const int32_t *task_of_inst, const void *x0, const void *sigma0,
+                 const mp_cem_options *opt, const void *noise, void *best_x, void *best_val, int32_t *nit,
+                 void *best_min_clear, uint8_t *best_flags, int mem)
+{
+    int rc = check_ctx(ctx);
+    if (rc) return rc;
+    if (!ctx->have_problem) return fail(ctx, MP_E_STATE, "mp_cem_solve: call mp_set_scene and mp_set_problem first");
+    if (n_inst < 0) return fail(ctx, MP_E_ARG, "mp_cem_solve: n_inst < 0");
+    if (n_inst == 0) return MP_OK;
+    if (!x0 || !sigma0 || !opt || !best_x || !best_val) return fail(ctx, MP_E_ARG, "mp_cem_solve: NULL argument");
+    if (mem != MP_MEM_HOST && mem != MP_MEM_DEVICE) return fail(ctx, MP_E_ARG, "mp_cem_solve: unknown mem kind");
+    if (opt->population_size < 2 || opt->population_size > 1024) return fail(ctx, MP_E_ARG, "population_size must be in 2..1024");
+    if (opt->max_iter < 1) return fail(ctx, MP_E_ARG, "max_iter must be >= 1");
+    if (!(opt->elite_frac > 0.0 && opt->elite_frac <= 1.0)) return fail(ctx, MP_E_ARG, "elite_frac must be in (0, 1]");
+    if (!(opt->alpha >= 0.0 && opt->alpha <= 1.0) || !(opt->min_sigma >= 0.0)) return fail(ctx, MP_E_ARG, "alpha in [0,1], min_sigma >= 0");
+    const mp_config &c = ctx->cfg;
+    const size_t es = esize(ctx), D = (size_t)(3 * c.n_free + c.n_yaw_free);
+    // instance -> task map on the device
+    std::vector<int32_t> tmap((size_t)n_inst);
+    const long long per = (n_inst + ctx->n_tasks - 1) / ctx->n_tasks;
+    for (int64_t i = 0; i < n_inst; ++i) {
+        // task_of_inst is a host pointer in both mem modes (it is bookkeeping, not data)
+        const long long t = task_of_inst ? task_of_inst[i] : i / per;
+        if (t < 0 || t >= ctx->n_tasks) return fail(ctx, MP_E_ARG, "mp_cem_solve: task of instance %lld out of range", (long long)i);
+        tmap[(size_t)i] = (int32_t)t;
+    }
+    if ((rc = upload(ctx, ctx->c_task, tmap.data(), tmap.size() * sizeof(int32_t)))) return rc;
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    const void *d_x0 = x0, *d_s0 = sigma0, *d_noise = noise;
+    if (mem == MP_MEM_HOST) {
+        if ((rc = upload(ctx, ctx->c_x0, x0, (size_t)n_inst * D * es))) return rc;
+        if ((rc = upload(ctx, ctx->c_s0, sigma0, (size_t)n_inst * D * es))) return rc;
+        d_x0 = ctx->c_x0.p; d_s0 = ctx->c_s0.p;
+        if (noise) {
+            if ((rc = upload(ctx, ctx->c_noise, noise, (size_t)opt->max_iter * n_inst * opt->population_size * D * es))) return rc;
+            d_noise = ctx->c_noise.p;
+        }
+    }
+    if (ctx->dtype == MP_F64)
+        return cem_solve<double>(ctx, n_inst, (const int32_t *)ctx->c_task.p, (const double *)d_x0, (const double *)d_s0, *opt,
+                                 (const double *)d_noise, (double *)best_x, (double *)best_val, nit, (double *)best_min_clear,
+                                 best_flags, mem);
+    return cem_solve<float>(ctx, n_inst, (const int32_t *)ctx->c_task.p, (const float *)d_x0, (const float *)d_s0, *opt,
+                            (const float *)d_noise, (float *)best_x, (float *)best_val, nit, (float *)best_min_clear, best_flags,
+                            mem);
 }
 
 }  // extern "C"

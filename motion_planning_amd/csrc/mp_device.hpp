@@ -445,6 +445,11 @@ template <int CTRL, int ROW_MASK, bool ZERO_FILL> __device__ __forceinline__ dou
     int hi = dpp32<CTRL, ROW_MASK, ZERO_FILL>(__double2hiint(v));
     return __hiloint2double(hi, lo);
 }
+template <int CTRL, int ROW_MASK, bool ZERO_FILL> __device__ __forceinline__ int dpp_mov(int v)
+{
+    return dpp32<CTRL, ROW_MASK, ZERO_FILL>(v);
+}
+__device__ __forceinline__ int read_lane63(int v) { return __builtin_amdgcn_readlane(v, 63); }
 __device__ __forceinline__ float read_lane63(float v) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63)); }
 __device__ __forceinline__ double read_lane63(double v)
 {

@@ -47,6 +47,10 @@ template <typename T> struct EvalArgs {
     const T *X;
     const int *task_of;
     long long cpt;
+    // batched optimisers: candidates come in groups (one CEM population per group)
+    int group_size;              // 0: not grouped
+    const int *group_task;       // [n / group_size] task of each group, or NULL (task 0)
+    const uint8_t *group_done;   // [n / group_size] 1: skip this group's candidates
     long long n;
     T *cost, *terms, *grad, *minc, *dist;
     uint8_t *flags;
@@ -92,7 +96,14 @@ __global__ void __launch_bounds__(256, MP_MIN_WAVES) eval_kernel(const EvalArgs<
     const T inv_du = T(1) / du, inv_h2 = T(1) / (T(2) * du);
 
     for (long long cand = (long long)blockIdx.x * wpb + wib; cand < a.n; cand += (long long)gridDim.x * wpb) {
-        long long tl = a.task_of ? (long long)a.task_of[cand] : (a.cpt > 0 ? cand / a.cpt : 0);
+        long long tl;
+        if (a.group_size > 0) {
+            const long long grp = cand / a.group_size;
+            if (a.group_done && a.group_done[grp]) continue;
+            tl = a.group_task ? (long long)a.group_task[grp] : 0;
+        } else {
+            tl = a.task_of ? (long long)a.task_of[cand] : (a.cpt > 0 ? cand / a.cpt : 0);
+        }
         const int t = __builtin_amdgcn_readfirstlane((int)tl);
         const DevTask<T> &tk = a.tasks[t];
         const T *x = a.X + cand * D;
@@ -618,6 +629,171 @@ __global__ void __launch_bounds__(256) box_sdf_kernel(long long n, const T *__re
         pose_setup(ps, pos[3 * i], pos[3 * i + 1], pos[3 * i + 2], c, s, ax, ay);
         int arg;
         out[i] = pose_distance(ps, ax, ay, az, boxes, nb, arg);
+    }
+}
+
+
+// ---- device-resident cross-entropy method (many instances in lock-step) ------------------
+// Restates _cem_optimize (geom/spline_opt.py:222-277) per instance: sample a population around
+// (mu, sigma), evaluate it with eval_kernel, keep the best candidate seen, refit (mu, sigma) to the
+// elite_count best members with alpha-smoothing, stop on |best - prev_best| < tol and max sigma < 0.03.
+struct Philox {
+    // Philox-4x32-10 counter-based generator (Salmon et al., SC'11): stateless, one call per 4 words
+    __device__ static void round(unsigned int (&c)[4], unsigned int k0, unsigned int k1)
+    {
+        const unsigned long long p0 = 0xD2511F53ull * c[0], p1 = 0xCD9E8D57ull * c[2];
+        const unsigned int h0 = (unsigned int)(p0 >> 32), l0 = (unsigned int)p0;
+        const unsigned int h1 = (unsigned int)(p1 >> 32), l1 = (unsigned int)p1;
+        c[0] = h1 ^ c[1] ^ k0; c[1] = l1; c[2] = h0 ^ c[3] ^ k1; c[3] = l0;
+    }
+    __device__ static void generate(unsigned long long seed, unsigned long long ctr_lo, unsigned long long ctr_hi,
+                                    unsigned int (&out)[4])
+    {
+        unsigned int k0 = (unsigned int)seed, k1 = (unsigned int)(seed >> 32);
+        out[0] = (unsigned int)ctr_lo; out[1] = (unsigned int)(ctr_lo >> 32);
+        out[2] = (unsigned int)ctr_hi; out[3] = (unsigned int)(ctr_hi >> 32);
+#pragma unroll
+        for (int r = 0; r < 10; ++r) {
+            round(out, k0, k1);
+            k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+        }
+    }
+};
+
+template <typename T> struct CemState {
+    T *mu, *sigma, *best_x;      // [n_inst x D]
+    T *best_val, *prev_best;     // [n_inst]
+    T *best_minc;                // [n_inst]
+    uint8_t *best_flags, *done;  // [n_inst]
+    int *nit;                    // [n_inst]
+    int *n_active;               // [1] instances still running after this generation
+};
+
+// X[i, p, :] = mu[i] + eps * sigma[i]; eps from `noise` (generation-major, parity mode) or Philox + Box-Muller
+template <typename T>
+__global__ void __launch_bounds__(256) cem_sample_kernel(long long n_inst, int pop, int D, CemState<T> st,
+                                                          const T *__restrict__ noise, unsigned long long seed, int gen,
+                                                          T *__restrict__ X)
+{
+    const long long total = n_inst * pop * D;
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
+        const long long inst = e / ((long long)pop * D);
+        if (st.done[inst]) continue;
+        const int d = (int)(e % D);
+        T eps;
+        if (noise) {
+            eps = noise[e];
+        } else {
+            unsigned int r[4];
+            Philox::generate(seed, (unsigned long long)e, (unsigned long long)gen, r);
+            const double u1 = ((double)r[0] * 4294967296.0 + (double)r[1] + 1.0) * (1.0 / 18446744073709551616.0);  // (0,1]
+            const double u2 = ((double)r[2] * 4294967296.0 + (double)r[3]) * (1.0 / 18446744073709551616.0);        // [0,1)
+            eps = (T)(::sqrt(-2.0 * ::log(u1)) * ::cospi(2.0 * u2));
+        }
+        X[e] = st.mu[inst * D + d] + eps * st.sigma[inst * D + d];
+    }
+}
+
+// one wave per instance: best-so-far, elite refit, stop rule
+template <typename T>
+__global__ void __launch_bounds__(256) cem_update_kernel(long long n_inst, int pop, int D, int n_elite, T alpha, T min_sigma,
+                                                          T tol, CemState<T> st, const T *__restrict__ X,
+                                                          const T *__restrict__ vals, const T *__restrict__ minc,
+                                                          const uint8_t *__restrict__ flags)
+{
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    const int lane = threadIdx.x & 63;
+    const int wib = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int wpb = (int)(blockDim.x >> 6);
+    T *V = reinterpret_cast<T *>(smem_raw) + (size_t)wib * pop;   // this wave's copy of the population costs
+    for (long long inst = (long long)blockIdx.x * wpb + wib; inst < n_inst; inst += (long long)gridDim.x * wpb) {
+        if (st.done[inst]) continue;
+        const T *v = vals + inst * pop;
+        const T *x = X + inst * (long long)pop * D;
+        // argmin (first minimum, NaN never wins) and LDS copy
+        T bv = Lim<T>::inf();
+        int bi = 0x7fffffff;
+        for (int p = lane; p < pop; p += 64) {
+            T val = v[p];
+            val = (val == val) ? val : Lim<T>::inf();
+            V[p] = val;
+            if (val < bv) { bv = val; bi = p; }
+        }
+        wave_lds_sync();
+        const T wmin = wave_min(bv);
+        int cand_i = (bv == wmin) ? bi : 0x7fffffff;
+        const int best_i = wave_min(cand_i);
+        T best_val = st.best_val[inst];
+        if (best_i < pop && wmin < best_val) {
+            best_val = wmin;
+            for (int d = lane; d < D; d += 64) st.best_x[inst * D + d] = x[(long long)best_i * D + d];
+            if (lane == 0) {
+                st.best_val[inst] = wmin;
+                st.best_minc[inst] = minc[inst * pop + best_i];
+                st.best_flags[inst] = flags[inst * pop + best_i];
+            }
+        }
+        // elite membership by rank (ties broken by index, like a stable partition)
+        unsigned int elite_bits = 0;  // bit j: member lane + 64 j is an elite
+        for (int p = lane, j = 0; p < pop; p += 64, ++j) {
+            const T mine = V[p];
+            int rank = 0;
+            for (int q = 0; q < pop; ++q) {
+                const T other = V[q];
+                rank += (other < mine || (other == mine && q < p)) ? 1 : 0;
+            }
+            if (rank < n_elite) elite_bits |= 1u << j;
+        }
+        // refit per dimension: mean, then population std (np.std, ddof = 0)
+        T max_sigma = T(0);
+        for (int d = 0; d < D; ++d) {
+            T acc = T(0);
+            for (int p = lane, j = 0; p < pop; p += 64, ++j)
+                if (elite_bits & (1u << j)) acc += x[(long long)p * D + d];
+            const T mean = wave_sum(acc) / (T)n_elite;
+            T acc2 = T(0);
+            for (int p = lane, j = 0; p < pop; p += 64, ++j)
+                if (elite_bits & (1u << j)) {
+                    const T e = x[(long long)p * D + d] - mean;
+                    acc2 += e * e;
+                }
+            const T sd = mp_sqrt(wave_sum(acc2) / (T)n_elite) + min_sigma;
+            const T mu_new = alpha * st.mu[inst * D + d] + (T(1) - alpha) * mean;
+            T sg_new = alpha * st.sigma[inst * D + d] + (T(1) - alpha) * sd;
+            sg_new = sg_new > min_sigma ? sg_new : min_sigma;
+            max_sigma = sg_new > max_sigma ? sg_new : max_sigma;
+            if (lane == 0) { st.mu[inst * D + d] = mu_new; st.sigma[inst * D + d] = sg_new; }
+        }
+        if (lane == 0) {
+            const T prev = st.prev_best[inst];
+            st.nit[inst] += 1;
+            const T diff = prev - best_val;
+            const bool stop = ((diff < T(0) ? -diff : diff) < tol) && (max_sigma < T(0.03));
+            if (stop) st.done[inst] = 1;
+            else atomicAdd(st.n_active, 1);
+            st.prev_best[inst] = best_val;
+        }
+        wave_lds_sync();
+    }
+}
+
+template <typename T>
+__global__ void cem_init_kernel(long long n_inst, int D, CemState<T> st, const T *__restrict__ x0, const T *__restrict__ sigma0,
+                                T min_sigma)
+{
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < n_inst * D; e += (long long)gridDim.x * blockDim.x) {
+        st.mu[e] = x0[e];
+        st.best_x[e] = x0[e];
+        const T sg = sigma0[e];
+        st.sigma[e] = sg > min_sigma ? sg : min_sigma;
+        if (e < n_inst) {
+            st.best_val[e] = Lim<T>::inf();
+            st.prev_best[e] = Lim<T>::inf();
+            st.best_minc[e] = Lim<T>::inf();
+            st.best_flags[e] = 0;
+            st.done[e] = 0;
+            st.nit[e] = 0;
+        }
     }
 }
 
