@@ -49,6 +49,7 @@ class DeviceBatch:
             self.ctx.set_cands_per_task(cands_per_task)
         self.problem = self.ctx.problem
         self.capacity = int(capacity)
+        self._stream = None
         dev = torch.device("cuda", self.device)
         D = self.problem.dim
         self.cost = torch.empty(capacity, dtype=self.tdtype, device=dev)
@@ -63,7 +64,10 @@ class DeviceBatch:
             raise ValueError("batch larger than the preallocated capacity")
         if X.dtype != self.tdtype or not X.is_cuda or not X.is_contiguous() or X.shape[1] != self.problem.dim:
             raise ValueError("X must be a contiguous CUDA tensor of the context dtype with D columns")
-        self.ctx.set_stream(torch.cuda.current_stream(self.device).cuda_stream)
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        if stream != self._stream:
+            self.ctx.set_stream(stream)
+            self._stream = stream
         self.ctx.eval_device(
             n, X.data_ptr(), self.cost.data_ptr(), self.terms.data_ptr() if self.terms is not None else 0,
             self.grad.data_ptr() if self.grad is not None else 0, self.min_clear.data_ptr(), self.flags.data_ptr(), 0,

@@ -62,3 +62,87 @@ def synthetic_candidates(problem: PathProblem, n: int, seed: int = 0, dtype=np.f
     rng = np.random.default_rng(seed)
     eps = rng.normal(size=(n, problem.dim))
     return np.ascontiguousarray(problem.x0[None, :] + eps * problem.sigma0[None, :], dtype=dtype)
+
+
+# ---- scenario-parallel workload (BASELINE config 5) -------------------------------------------
+# Randomised wall-building steps in the spirit of the reference's example/generate_scenarios.py:
+# 0.9 x 0.6 x 0.6 blocks on a block-size-aligned grid over the 4 x 4 x 0.1 table, the moving block
+# is to be placed against already placed blocks (on the ground, beside, on top, in a gap), goal
+# normals come from the faces it will touch, and the start follows the reference's rule
+# (goal - 1.2 * approach direction, lifted to max(goal_z + 0.9, 1.25); generate_scenarios.py:144-150).
+_BLOCK = (0.9, 0.6, 0.6)
+_TABLE_TOP = 0.1
+
+
+def generate_wall_scenario(rng: np.random.Generator):
+    """One random placement step: returns (blocks, start, goal, goal_normals)."""
+    gx, gy, gz = _BLOCK
+    n_placed = int(rng.integers(1, 13))
+    occupied = {}
+    # grow a small wall: new blocks go on the ground next to the wall or on top of a supported cell
+    ci, cj = int(rng.integers(-1, 2)), int(rng.integers(-2, 3))
+    occupied[(ci, cj, 0)] = True
+    guard = 0
+    while len(occupied) < n_placed and guard < 200:
+        guard += 1
+        i, j, k = list(occupied)[int(rng.integers(0, len(occupied)))]
+        move = int(rng.integers(0, 5))
+        cand = [(i + 1, j, k), (i - 1, j, k), (i, j + 1, k), (i, j - 1, k), (i, j, k + 1)][move]
+        if cand in occupied or abs(cand[0]) > 1 or abs(cand[1]) > 2 or cand[2] > 2:
+            continue
+        if cand[2] > 0 and (cand[0], cand[1], cand[2] - 1) not in occupied:
+            continue
+        occupied[cand] = True
+    # goal: a free, supported cell that touches the wall
+    options = []
+    for (i, j, k) in occupied:
+        for cand in [(i + 1, j, k), (i - 1, j, k), (i, j + 1, k), (i, j - 1, k), (i, j, k + 1)]:
+            if cand in occupied or abs(cand[0]) > 1 or abs(cand[1]) > 2 or cand[2] > 2:
+                continue
+            if cand[2] > 0 and (cand[0], cand[1], cand[2] - 1) not in occupied:
+                continue
+            if (cand[0], cand[1], cand[2] + 1) in occupied:
+                continue  # must be reachable from above
+            options.append(cand)
+    if not options:
+        options = [(ci, cj, max(k for (i, j, k) in occupied if (i, j) == (ci, cj)) + 1)]
+    gi, gj, gk = options[int(rng.integers(0, len(options)))]
+
+    def centre(i, j, k):
+        return (i * gx, j * gy, _TABLE_TOP + 0.5 * gz + k * gz)
+
+    goal = centre(gi, gj, gk)
+    normals = []
+    for (di, dj, n) in [(-1, 0, (1.0, 0.0, 0.0)), (1, 0, (-1.0, 0.0, 0.0)), (0, -1, (0.0, 1.0, 0.0)), (0, 1, (0.0, -1.0, 0.0))]:
+        if (gi + di, gj + dj, gk) in occupied:
+            normals.append(n)
+    normals.append((0.0, 0.0, 1.0))  # supported from below (table or block)
+    s = np.sum(np.asarray(normals), axis=0)
+    nrm = float(np.linalg.norm(s))
+    approach = -s / nrm if nrm > 1e-12 else np.array([0.0, 0.0, -1.0])
+    start = (goal[0] - 1.2 * approach[0], goal[1] - 1.2 * approach[1], max(goal[2] + 0.9, 1.25))
+    blocks = [Block(size=(4.0, 4.0, 0.1), position=(0.0, 0.0, 0.05), object_id="table")]
+    for n, (i, j, k) in enumerate(sorted(occupied)):
+        blocks.append(Block(size=_BLOCK, position=centre(i, j, k), object_id=f"block_{n + 1}"))
+    return blocks, start, goal, np.asarray(normals, dtype=float)
+
+
+def wall_scenario_problems(basis_fn, n_scenarios: int, seed: int = 2, n_samples: int = 101):
+    """``n_scenarios`` PathProblems with BASE_CONFIG (one shared mp_config, per-scenario task data)."""
+    rng = np.random.default_rng(seed)
+    cache = {}
+
+    def cached_basis(n, k, S):
+        key = (n, k, S)
+        if key not in cache:
+            cache[key] = basis_fn(n, k, S)
+        return cache[key]
+
+    cfg = dict(BASE_CONFIG)
+    cfg["n_samples_curve"] = int(n_samples)
+    out = []
+    for _ in range(n_scenarios):
+        blocks, start, goal, normals = generate_wall_scenario(rng)
+        out.append(build_path_problem(BoxList(blocks), start, goal, cached_basis, moving_block_size=_BLOCK,
+                                      start_yaw_deg=0.0, goal_yaw_deg=0.0, goal_approach_normals=normals, **cfg))
+    return out
