@@ -72,7 +72,7 @@ def main():
     import torch.distributed as dist
 
     from motion_planning_amd import _native
-    from motion_planning_amd.batch import DeviceBatch, pack_results
+    from motion_planning_amd.batch import DeviceBatch
     from motion_planning_amd.synthetic import synthetic_candidates, synthetic_problem
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -94,20 +94,19 @@ def main():
     X = torch.from_numpy(Xh).cuda()
     db = DeviceBatch(problem, N_CAND, device=local_rank if world > 1 else 0, dtype=np_dtype, want_grad=True)
     gather_buf = [torch.empty(world * N_CAND, 3, dtype=tdtype, device="cuda") for _ in range(2)] if world > 1 else None
-    comm_stream = torch.cuda.Stream() if world > 1 else None
+    packed_buf = [torch.empty(N_CAND, 3, dtype=tdtype, device="cuda") for _ in range(2)] if world > 1 else None
 
     def step(i, pending):
         out = db.evaluate(X)
         if world > 1:
-            packed = pack_results(out["cost"], out["min_clear"], out["flags"])
-            ev = torch.cuda.Event()
-            ev.record()
-            with torch.cuda.stream(comm_stream):
-                comm_stream.wait_event(ev)
-                packed.record_stream(comm_stream)
-                pending.append(dist.all_gather_into_tensor(gather_buf[i % 2], packed, async_op=True))
-                if len(pending) > 2:
-                    pending.pop(0).wait()
+            # double-buffered: the collective of step i runs on RCCL's stream while step i+1 computes
+            if len(pending) >= 2:
+                pending.pop(0).wait()
+            pk = packed_buf[i % 2]
+            pk[:, 0].copy_(out["cost"])
+            pk[:, 1].copy_(out["min_clear"])
+            pk[:, 2].copy_(out["flags"])
+            pending.append(dist.all_gather_into_tensor(gather_buf[i % 2], pk, async_op=True))
         return out
 
     def sync():
@@ -128,7 +127,6 @@ def main():
         step(i, pend)
     for w in pend:
         w.wait()
-    torch.cuda.current_stream().wait_stream(comm_stream) if world > 1 else None
     sync()
     elapsed = time.perf_counter() - t0
     if world > 1:
