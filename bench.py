@@ -153,6 +153,18 @@ def main():
         except Exception:
             traffic = None
 
+    executed = None
+    pfile = ROOT / "profiles" / "r01_pmc" / "summary.json"
+    if pfile.exists() and args.dtype == "f64":
+        try:
+            g = json.loads(pfile.read_text())["grad"]
+            executed = {"valu_insts_per_eval": g["SQ_INSTS_VALU"] / N_CAND, "salu_insts_per_eval": g["SQ_INSTS_SALU"] / N_CAND,
+                        "lds_insts_per_eval": g["SQ_INSTS_LDS"] / N_CAND,
+                        "valu_busy_frac": g["SQ_ACTIVE_INST_VALU"] * 4 / (g["GRBM_GUI_ACTIVE"] / 8 * 1024),
+                        "source": "profiles/r01_pmc/summary.json (rocprofv3 --pmc passes of tools/prof_run.py, same kernel and batch)"}
+        except Exception:
+            executed = None
+
     extras = {}
     if rank == 0 and world == 1:
         db_c = DeviceBatch(problem, N_CAND, dtype=np_dtype, want_grad=False)
@@ -200,8 +212,11 @@ def main():
                          "kernel_ms": kern_ms, "algorithmic_flops_per_eval": flops // N_CAND,
                          "algorithmic_bytes_per_eval": alg_bytes // N_CAND,
                          "hbm_achieved_GBps": alg_bytes / (kern_ms * 1e-3) / 1e9, "hbm_peak_GBps": HBM_PEAK_GBPS,
-                         "note": "compute-bound on the FP64 vector ALU (no MFMA-shaped work, 145 B/eval of HBM traffic); "
-                                 "peak = datasheet FP64 vector rate"},
+                         "executed": executed,
+                         "note": "bound = FP64 vector ALU (SURVEY 8d: no MFMA-shaped work, 145 B/eval of HBM traffic); peak = "
+                                 "datasheet FP64 vector rate; achieved counts the ALGORITHMIC (brute-force) flops per launch, the "
+                                 "kernel culls most pair evaluations with a conservative bound, so frac is useful throughput "
+                                 "against the brute-force roofline, not ALU utilisation (see executed / DESIGN.md 4)"},
             "extras": extras,
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -150,8 +150,11 @@ const char *mp_last_error(const mp_ctx *ctx); /* ctx may be NULL: last create er
 int mp_api_version(void);
 
 /* Use an externally owned hipStream_t (e.g. torch's current stream) for all work of
- * this context; NULL restores the context's own stream. */
+ * this context.  The handle is used as given: NULL is HIP's default (null) stream, which
+ * is what torch reports as its default stream on ROCm.  mp_use_own_stream() goes back to
+ * the non-blocking stream the context created for itself. */
 int mp_set_stream(mp_ctx *ctx, void *hip_stream);
+int mp_use_own_stream(mp_ctx *ctx);
 int mp_synchronize(mp_ctx *ctx);
 
 /* HIP-event timer on the context's stream (bench.py times kernels with it). */

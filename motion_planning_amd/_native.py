@@ -53,6 +53,7 @@ def load():
     lib.mp_create.argtypes = [C.c_int, C.c_int, C.POINTER(vp)]
     lib.mp_destroy.argtypes = [vp]
     lib.mp_set_stream.argtypes = [vp, vp]
+    lib.mp_use_own_stream.argtypes = [vp]
     lib.mp_synchronize.argtypes = [vp]
     lib.mp_timer_start.argtypes = [vp]
     lib.mp_timer_stop.argtypes = [vp, C.POINTER(C.c_float)]
@@ -65,7 +66,7 @@ def load():
     lib.mp_point_sdf.argtypes = [vp, i64, vp, C.c_double, i32, i32, vp, C.c_int]
     lib.mp_box_sdf.argtypes = [vp, i64, vp, vp, vp, i32, i32, vp, C.c_int]
     lib.mp_cem_solve.argtypes = [vp, i64, vp, vp, vp, C.POINTER(abi.MpCemOptions), vp, vp, vp, vp, vp, vp, C.c_int]
-    for name in ("mp_create", "mp_destroy", "mp_set_stream", "mp_synchronize", "mp_timer_start", "mp_timer_stop",
+    for name in ("mp_create", "mp_destroy", "mp_set_stream", "mp_use_own_stream", "mp_synchronize", "mp_timer_start", "mp_timer_stop",
                  "mp_set_scene", "mp_set_problem", "mp_build_basis", "mp_get_basis", "mp_set_cands_per_task",
                  "mp_eval", "mp_point_sdf", "mp_box_sdf", "mp_cem_solve"):
         getattr(lib, name).restype = C.c_int
@@ -124,7 +125,12 @@ class Context:
             pass
 
     def set_stream(self, stream_ptr: Optional[int]) -> None:
-        self._check(self.lib.mp_set_stream(self._h, C.c_void_p(stream_ptr or 0)))
+        """An int is a hipStream_t handle used as given (0 = the default stream, torch's default on
+        ROCm); None goes back to the context's own stream."""
+        if stream_ptr is None:
+            self._check(self.lib.mp_use_own_stream(self._h))
+        else:
+            self._check(self.lib.mp_set_stream(self._h, C.c_void_p(int(stream_ptr))))
 
     def synchronize(self) -> None:
         self._check(self.lib.mp_synchronize(self._h))

@@ -49,7 +49,7 @@ class DeviceBatch:
             self.ctx.set_cands_per_task(cands_per_task)
         self.problem = self.ctx.problem
         self.capacity = int(capacity)
-        self._stream = None
+        self._stream = -1   # no stream bound yet (0 is a valid handle: the default stream)
         dev = torch.device("cuda", self.device)
         D = self.problem.dim
         self.cost = torch.empty(capacity, dtype=self.tdtype, device=dev)
@@ -176,3 +176,36 @@ def solve_scenarios_cem(problems: Sequence[PathProblem], restarts: int = 32, dev
         "nit": res["nit"].reshape(n_s, restarts),
         "all_fun": fun,
     }
+
+
+def refine_gradient(db: DeviceBatch, X: torch.Tensor, iters: int = 20, step0: float = 0.05, shrink: float = 0.5,
+                    grow: float = 1.3, scale: Optional[torch.Tensor] = None) -> Dict[str, torch.Tensor]:
+    """Batched local refinement with the analytic gradient (the reference has no counterpart: its local
+    stage is the derivative-free Powell search, geom/spline_opt.py:339-344).
+
+    Per candidate: a normalised-gradient step with its own step length, accepted only if the cost drops
+    (otherwise the step shrinks) — monotone descent that tolerates the kinks of the sub-gradient.
+    ``scale`` (D,) preconditions the mixed units of x (metres and degrees); default: the problem's sigma0.
+    Everything stays on the GPU; one ``mp_eval`` launch per iteration."""
+    if db.grad is None:
+        raise ValueError("DeviceBatch was created without want_grad")
+    x = X.clone()
+    out = db.evaluate(x)
+    cost, grad = out["cost"].clone(), out["grad"].clone()
+    minc, flags = out["min_clear"].clone(), out["flags"].clone()
+    step = torch.full_like(cost, float(step0))
+    if scale is None:
+        scale = torch.as_tensor(db.problem.sigma0, dtype=x.dtype, device=x.device)
+    for _ in range(iters):
+        gs = grad * scale[None, :]
+        gnorm = gs.norm(dim=1, keepdim=True).clamp_min(1e-30)
+        trial = (x - step[:, None] * scale[None, :] * gs / gnorm).contiguous()
+        o = db.evaluate(trial)
+        better = o["cost"] < cost
+        x = torch.where(better[:, None], trial, x)
+        grad = torch.where(better[:, None], o["grad"], grad)
+        minc = torch.where(better, o["min_clear"], minc)
+        flags = torch.where(better, o["flags"], flags)
+        cost = torch.where(better, o["cost"], cost)
+        step = torch.where(better, step * grow, step * shrink)
+    return {"x": x, "cost": cost, "min_clear": minc, "flags": flags}

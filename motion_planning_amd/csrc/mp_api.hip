@@ -520,10 +520,20 @@ int mp_set_stream(mp_ctx *ctx, void *hip_stream)
 {
     int rc = check_ctx(ctx);
     if (rc) return rc;
-    hipStream_t next = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
+    hipStream_t next = (hipStream_t)hip_stream;
     if (next == ctx->stream) return MP_OK;
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));  // work queued on the old stream finishes first
     ctx->stream = next;
+    return MP_OK;
+}
+
+int mp_use_own_stream(mp_ctx *ctx)
+{
+    int rc = check_ctx(ctx);
+    if (rc) return rc;
+    if (ctx->stream == ctx->own_stream) return MP_OK;
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->stream = ctx->own_stream;
     return MP_OK;
 }
 

@@ -320,3 +320,53 @@ def test_device_cem_many_instances_with_device_rng(native):
     np.testing.assert_allclose(again["cost"], a["fun"], rtol=1e-12)
     np.testing.assert_array_equal((again["flags"] & 2) != 0, a["solved"])
     ctx.close()
+
+
+def test_config4_shard_properties(native, oracle_lib):
+    """BASELINE config 4, one GPU's shard of the 8-GPU job (131,072 candidates x 256 samples x 2,000 boxes):
+    determinism, flag consistency and a strided checksum against the brute-force oracle."""
+    import torch
+
+    from motion_planning_amd.batch import DeviceBatch, shard_bounds
+    from motion_planning_amd.synthetic import synthetic_candidates, synthetic_problem
+
+    prob = synthetic_problem(native.build_basis, 2000, 256, seed=1, size_range=(0.05, 0.3))
+    lo, hi = shard_bounds(1_048_576, 3, 8)
+    n = hi - lo
+    assert n == 131072
+    Xh = synthetic_candidates(prob, n, seed=1003)
+    X = torch.from_numpy(Xh).cuda()
+    db = DeviceBatch(prob, n, want_grad=True)
+    o = db.evaluate(X)
+    torch.cuda.synchronize()
+    cost, flags, minc, grad = (o[k].cpu().numpy().copy() for k in ("cost", "flags", "min_clear", "grad"))
+    o2 = db.evaluate(X)
+    torch.cuda.synchronize()
+    assert np.array_equal(o2["cost"].cpu().numpy(), cost) and np.array_equal(o2["min_clear"].cpu().numpy(), minc)
+    assert np.array_equal(flags, ((minc < 0) * 1 + (minc >= prob.required_clearance) * 2).astype(np.uint8))
+    assert np.all(np.isfinite(cost)) and np.all(np.isfinite(grad))
+    idx = np.arange(0, n, 4099)
+    ref = oracle_lib.evaluate(prob, Xh[idx])
+    assert np.array_equal(ref["min_clear"], minc[idx]) and np.array_equal(ref["flags"], flags[idx])
+    assert H.rel_err(cost[idx], ref["cost"]).max() < 1e-9
+    assert (np.abs(grad[idx] - ref["grad"]) / np.abs(ref["grad"]).max(axis=1, keepdims=True)).max() < 1e-9
+    db.close()
+
+
+def test_gradient_refinement_descends(native):
+    import torch
+
+    from motion_planning_amd.batch import DeviceBatch, refine_gradient
+    from motion_planning_amd.synthetic import synthetic_candidates, synthetic_problem
+
+    prob = synthetic_problem(native.build_basis, 50, 64, 0)
+    n = 4096
+    X = torch.from_numpy(prob.x0 + 0.2 * prob.sigma0 * np.random.default_rng(2).normal(size=(n, prob.dim))).cuda()
+    db = DeviceBatch(prob, n, want_grad=True)
+    start = db.evaluate(X)["cost"].clone()
+    res = refine_gradient(db, X, iters=30)
+    assert bool((res["cost"] <= start).all())
+    assert float((res["cost"] < 0.9 * start).double().mean()) > 0.5          # most candidates improve by > 10 %
+    again = db.evaluate(res["x"].contiguous())
+    assert torch.equal(again["cost"], res["cost"]) and torch.equal(again["flags"], res["flags"])
+    db.close()

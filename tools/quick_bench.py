@@ -46,3 +46,13 @@ if __name__ == "__main__":
         check(p4, 128, np.float64)
         ms = bench(p4, 8192, np.float64, True, steps=3)
         print(f"config4-shaped fp64 grad: {ms:.3f} ms / 8192 -> {8192/ms*1e3:.3e} evals/s")
+
+    # host-buffer path of mp_eval (PCIe + staging inclusive), for DESIGN.md §7
+    import time
+    ctx = _native.Context(0, np.float64); ctx.set_problem(p3)
+    Xh = synthetic_candidates(p3, n, 2)
+    ctx.eval(Xh, want_terms=False, want_grad=True)
+    t0 = time.perf_counter()
+    for _ in range(5): ctx.eval(Xh, want_terms=False, want_grad=True)
+    dt = (time.perf_counter() - t0) / 5
+    print(f"config3 fp64 grad, HOST buffers in/out: {dt*1e3:.3f} ms -> {n/dt:.3e} evals/s")
