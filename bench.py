@@ -78,10 +78,18 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # rehearsal knobs (one-GPU box): MP_BENCH_ONE_DEVICE=1 puts every rank on cuda:0, MP_BENCH_BACKEND=gloo
+    # swaps RCCL for gloo; the driver's runs use neither
+    if os.environ.get("MP_BENCH_ONE_DEVICE") == "1":
+        local_rank = 0
+    backend = os.environ.get("MP_BENCH_BACKEND", "nccl")
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
     else:
         torch.cuda.set_device(0)
     if args.gpus != world and rank == 0 and world > 1:
@@ -92,7 +100,7 @@ def main():
     problem = synthetic_problem(_native.build_basis, N_BOXES, N_SAMPLES, seed=0)
     Xh = synthetic_candidates(problem, N_CAND, seed=100 + rank, dtype=np_dtype)   # this rank's index shard
     X = torch.from_numpy(Xh).cuda()
-    db = DeviceBatch(problem, N_CAND, device=local_rank if world > 1 else 0, dtype=np_dtype, want_grad=True)
+    db = DeviceBatch(problem, N_CAND, device=local_rank, dtype=np_dtype, want_grad=True)
     gather_buf = [torch.empty(world * N_CAND, 3, dtype=tdtype, device="cuda") for _ in range(2)] if world > 1 else None
     packed_buf = [torch.empty(N_CAND, 3, dtype=tdtype, device="cuda") for _ in range(2)] if world > 1 else None
 
