@@ -163,9 +163,13 @@ int mp_timer_stop(mp_ctx *ctx, float *elapsed_ms); /* synchronises on the stop e
 
 /* ---- scene: replaces Scene.blocks / Block (geom/scene.py:10-45, geom/blocks.py:8-21)
  * SoA host arrays of box centres and HALF extents.  quat_xyzw may be NULL (all
- * identity).  Static boxes must be axis-aligned in this version: any non-identity
- * quaternion returns MP_E_UNSUPPORTED (every shipped scenario is axis-aligned,
- * SURVEY.md §0 F5).  n_boxes == 0 is legal: distances are +inf (scene.py:112-113). */
+ * identity).  A static box may be rotated about z (x = y = 0 in its quaternion,
+ * Block.quat of geom/blocks.py:8-21): its (cos, sin) are taken as R00 = 1 - 2zz,
+ * R10 = 2wz like the reference's quat_to_rot (geom/utils.py:3-14) and every pair is
+ * evaluated in the box's own frame.  A box tilted about x or y returns
+ * MP_E_UNSUPPORTED (no shipped scenario has one); a quaternion
+ * that is not of unit length returns MP_E_ARG.
+ * n_boxes == 0 is legal: distances are +inf (scene.py:112-113). */
 int mp_set_scene(mp_ctx *ctx, int32_t n_boxes, const double *cx, const double *cy,
                  const double *cz, const double *hx, const double *hy, const double *hz,
                  const double *quat_xyzw /* [n_boxes x 4] or NULL */);

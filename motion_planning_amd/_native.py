@@ -13,7 +13,7 @@ from typing import Optional, Sequence
 import numpy as np
 
 from . import _abi as abi
-from .problem import PathProblem
+from .problem import PathProblem, as_boxes8
 
 import os
 
@@ -144,10 +144,16 @@ class Context:
         return float(ms.value)
 
     # -- scene / problem --
-    def set_scene(self, boxes6: np.ndarray) -> None:
-        b = np.ascontiguousarray(boxes6, dtype=np.float64).reshape(-1, 6)
+    def set_scene(self, boxes: np.ndarray) -> None:
+        """(B,6) rows cx,cy,cz,hx,hy,hz, or (B,8) with the (z, w) of each box's yaw-only quaternion appended."""
+        b = as_boxes8(boxes)
         cols = [np.ascontiguousarray(b[:, i]) for i in range(6)]
-        self._check(self.lib.mp_set_scene(self._h, b.shape[0], *[_p(c) for c in cols], None))
+        quat = None
+        if b.shape[0] and not (np.all(b[:, 6] == 0.0) and np.all(b[:, 7] == 1.0)):
+            quat = np.zeros((b.shape[0], 4), dtype=np.float64)
+            quat[:, 2] = b[:, 6]
+            quat[:, 3] = b[:, 7]
+        self._check(self.lib.mp_set_scene(self._h, b.shape[0], *[_p(c) for c in cols], _p(quat)))
         self.n_boxes = int(b.shape[0])
 
     def set_problem(self, problems: Sequence[PathProblem] | PathProblem, upload_scene: bool = True) -> None:
@@ -156,7 +162,7 @@ class Context:
             problems = [problems]
         p0 = problems[0]
         if upload_scene:
-            self.set_scene(np.vstack([p.boxes for p in problems]))
+            self.set_scene(np.vstack([as_boxes8(p.boxes) for p in problems]))
         cfg = p0.config_struct()
         tasks = (abi.MpTask * len(problems))()
         off = 0

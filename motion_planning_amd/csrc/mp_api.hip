@@ -39,6 +39,7 @@ struct mp_ctx {
     DevBuf boxes, boxes32, groups;
     std::vector<double> h_boxes;  // host copy of the scene (n x 6) for the per-task bound tables
     float scene_radius = 0.f;
+    int has_rot = 0;              // any static box with a yaw of its own
     int n_boxes = 0;
     bool have_scene = false;
 
@@ -197,23 +198,32 @@ template <typename T> void to_vec(const double *src, size_t n, std::vector<T> &o
 }
 
 template <typename T> int upload_scene(mp_ctx *ctx, int n, const double *cx, const double *cy, const double *cz,
-                                        const double *hx, const double *hy, const double *hz)
+                                        const double *hx, const double *hy, const double *hz, const double *cb,
+                                        const double *sb)
 {
     std::vector<mp::BoxRec<T>> rec((size_t)std::max(n, 1));
+    bool any_rot = false;
     for (int i = 0; i < n; ++i) {
         rec[i].cx = (T)cx[i]; rec[i].cy = (T)cy[i]; rec[i].cz = (T)cz[i];
         rec[i].hx = (T)hx[i]; rec[i].hy = (T)hy[i]; rec[i].hz = (T)hz[i];
-        rec[i].pad0 = T(0); rec[i].pad1 = T(0);
+        rec[i].cb = (T)cb[i]; rec[i].sb = (T)sb[i];
+        any_rot = any_rot || !(cb[i] == 1.0 && sb[i] == 0.0);
     }
     int rc = upload(ctx, ctx->boxes, rec.data(), (size_t)n * sizeof(mp::BoxRec<T>));
     if (rc) return rc;
-    // host copy + scene radius (scales the slack of the fp32 bound pass); the fp32 tables are built per task
+    ctx->has_rot = any_rot ? 1 : 0;
+    // host copy (centre + half extents of each box's WORLD AABB) + scene radius (scales the slack of the fp32
+    // bound pass); the fp32 tables are built per task.  The AABB of a yaw-rotated box bounds the box, so the
+    // bound pass stays a valid lower bound of the distance.
     ctx->h_boxes.resize((size_t)n * 6);
     double radius = 0.0;
     for (int i = 0; i < n; ++i) {
         double *r = &ctx->h_boxes[(size_t)i * 6];
-        r[0] = cx[i]; r[1] = cy[i]; r[2] = cz[i]; r[3] = hx[i]; r[4] = hy[i]; r[5] = hz[i];
-        radius = std::max({radius, std::fabs(cx[i]) + hx[i], std::fabs(cy[i]) + hy[i], std::fabs(cz[i]) + hz[i]});
+        const double ac = std::fabs(cb[i]), as = std::fabs(sb[i]);
+        const double hxw = (cb[i] == 1.0 && sb[i] == 0.0) ? hx[i] : (ac * hx[i] + as * hy[i]) * (1.0 + 1e-12);
+        const double hyw = (cb[i] == 1.0 && sb[i] == 0.0) ? hy[i] : (as * hx[i] + ac * hy[i]) * (1.0 + 1e-12);
+        r[0] = cx[i]; r[1] = cy[i]; r[2] = cz[i]; r[3] = hxw; r[4] = hyw; r[5] = hz[i];
+        radius = std::max({radius, std::fabs(cx[i]) + hxw, std::fabs(cy[i]) + hyw, std::fabs(cz[i]) + hz[i]});
     }
     ctx->scene_radius = (float)radius;
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));  // rec is a local
@@ -327,16 +337,23 @@ template <typename T> int upload_problem(mp_ctx *ctx, const mp_task *tasks)
     return MP_OK;
 }
 
-template <typename T, int MODEL, bool GRAD>
-int launch_eval_k(mp_ctx *ctx, const mp::EvalArgs<T> &args, int wpb, int blocks, size_t lds_bytes)
+template <typename T, int MODEL, bool GRAD, bool ROT>
+int launch_eval_r(mp_ctx *ctx, const mp::EvalArgs<T> &args, int wpb, int blocks, size_t lds_bytes)
 {
-    auto kern = mp::eval_kernel<T, MODEL, GRAD>;
+    auto kern = mp::eval_kernel<T, MODEL, GRAD, ROT>;
     if (lds_bytes > 65536)
         HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                          (int)lds_bytes));
     hipLaunchKernelGGL(kern, dim3(blocks), dim3(64 * wpb), lds_bytes, ctx->stream, args);
     HIP_TRY(ctx, hipGetLastError());
     return MP_OK;
+}
+
+template <typename T, int MODEL, bool GRAD>
+int launch_eval_k(mp_ctx *ctx, const mp::EvalArgs<T> &args, int wpb, int blocks, size_t lds_bytes)
+{
+    return ctx->has_rot ? launch_eval_r<T, MODEL, GRAD, true>(ctx, args, wpb, blocks, lds_bytes)
+                        : launch_eval_r<T, MODEL, GRAD, false>(ctx, args, wpb, blocks, lds_bytes);
 }
 
 template <typename T>
@@ -571,17 +588,26 @@ int mp_set_scene(mp_ctx *ctx, int32_t n_boxes, const double *cx, const double *c
     if (rc) return rc;
     if (n_boxes < 0) return fail(ctx, MP_E_ARG, "mp_set_scene: n_boxes < 0");
     if (n_boxes > 0 && (!cx || !cy || !cz || !hx || !hy || !hz)) return fail(ctx, MP_E_ARG, "mp_set_scene: NULL array");
+    std::vector<double> cb((size_t)std::max(n_boxes, 1), 1.0), sb((size_t)std::max(n_boxes, 1), 0.0);
     for (int i = 0; i < n_boxes; ++i) {
         if (!(hx[i] >= 0.0 && hy[i] >= 0.0 && hz[i] >= 0.0))
             return fail(ctx, MP_E_ARG, "mp_set_scene: box %d has a negative or NaN half extent", i);
         if (quat_xyzw) {
             const double *q = quat_xyzw + 4 * (size_t)i;
-            if (!(q[0] == 0.0 && q[1] == 0.0 && q[2] == 0.0 && std::fabs(q[3]) == 1.0))
-                return fail(ctx, MP_E_UNSUPPORTED, "mp_set_scene: box %d is rotated; static boxes must be axis aligned", i);
+            if (!(q[0] == 0.0 && q[1] == 0.0))
+                return fail(ctx, MP_E_UNSUPPORTED, "mp_set_scene: box %d is tilted; static boxes may only be rotated about z", i);
+            const double nn = q[2] * q[2] + q[3] * q[3];
+            if (!(std::fabs(nn - 1.0) <= 1e-9))
+                return fail(ctx, MP_E_ARG, "mp_set_scene: box %d has a quaternion that is not of unit length", i);
+            // R00 / R10 of the reference's quat_to_rot (geom/utils.py:3-14) for a pure-yaw quaternion
+            if (!(q[2] == 0.0)) {
+                cb[i] = 1.0 - 2.0 * (q[2] * q[2]);
+                sb[i] = 2.0 * (q[3] * q[2]);
+            }
         }
     }
-    rc = ctx->dtype == MP_F64 ? upload_scene<double>(ctx, n_boxes, cx, cy, cz, hx, hy, hz)
-                              : upload_scene<float>(ctx, n_boxes, cx, cy, cz, hx, hy, hz);
+    rc = ctx->dtype == MP_F64 ? upload_scene<double>(ctx, n_boxes, cx, cy, cz, hx, hy, hz, cb.data(), sb.data())
+                              : upload_scene<float>(ctx, n_boxes, cx, cy, cz, hx, hy, hz, cb.data(), sb.data());
     if (rc) return rc;
     ctx->n_boxes = n_boxes;
     ctx->have_scene = true;
@@ -748,11 +774,11 @@ int mp_point_sdf(mp_ctx *ctx, int64_t n, const void *pts, double point_radius, i
     if (ctx->dtype == MP_F64)
         hipLaunchKernelGGL(mp::point_sdf_kernel<double>, dim3(blocks), dim3(256), 0, ctx->stream, (long long)n,
                            (const double *)d_pts, (const mp::BoxRec<double> *)ctx->boxes.p + box_begin, box_count,
-                           point_radius, (double *)d_out);
+                           point_radius, ctx->has_rot, (double *)d_out);
     else
         hipLaunchKernelGGL(mp::point_sdf_kernel<float>, dim3(blocks), dim3(256), 0, ctx->stream, (long long)n,
                            (const float *)d_pts, (const mp::BoxRec<float> *)ctx->boxes.p + box_begin, box_count,
-                           (float)point_radius, (float *)d_out);
+                           (float)point_radius, ctx->has_rot, (float *)d_out);
     HIP_TRY(ctx, hipGetLastError());
     if (mem == MP_MEM_HOST) {
         HIP_TRY(ctx, hipMemcpyAsync(out, d_out, (size_t)n * es, hipMemcpyDeviceToHost, ctx->stream));

@@ -121,7 +121,23 @@ template <typename T> __device__ __forceinline__ T rect_d2(T x, T y, T hx, T hy)
 
 // One (pose, box) pair.  sep == true: v = squared distance; sep == false: v = minus the
 // minimum SAT overlap (<= 0).
-template <typename T> struct BoxRec { T cx, cy, cz, hx, hy, hz, pad0, pad1; };
+// cb, sb = cos / sin of the box's own yaw (1, 0 = axis aligned)
+template <typename T> struct BoxRec { T cx, cy, cz, hx, hy, hz, cb, sb; };
+
+// A yaw-rotated static box is handled in the box's own frame: relative position R_b^T (p - c_b) and
+// relative rotation theta - theta_b (distances are invariant).  On return (px, py) is relative to the
+// box centre, so the pair is evaluated against a box centred at (0, 0, cz).  With cb = 1, sb = 0 every
+// value equals the axis-aligned one bit for bit (x*1 and x + (+-0) are exact).
+template <typename T>
+__device__ __forceinline__ void to_box_frame(const BoxRec<T> &bx, T &px, T &py, T &c, T &s)
+{
+    const T dxw = px - bx.cx, dyw = py - bx.cy;
+    px = mp_fma(bx.sb, dyw, bx.cb * dxw);
+    py = mp_fma(bx.cb, dyw, -(bx.sb * dxw));
+    const T cr = mp_fma(s, bx.sb, c * bx.cb);
+    const T sr = mp_fma(-c, bx.sb, s * bx.cb);
+    c = cr; s = sr;
+}
 
 template <typename T> struct PairOut {
     T gx, gy, gax, gay, gz, gsat, dx, dy, dz, lx, ly, w1x, w1y, w2x, w2y;
@@ -156,13 +172,13 @@ template <typename T> __device__ __forceinline__ BoxRec<T> load_box_uniform(cons
     CPtr p = (CPtr)(unsigned long long)(boxes + i);
     BoxRec<T> r;
     r.cx = p[0]; r.cy = p[1]; r.cz = p[2]; r.hx = p[3]; r.hy = p[4]; r.hz = p[5];
-    r.pad0 = T(0); r.pad1 = T(0);
+    r.cb = p[6]; r.sb = p[7];
     return r;
 }
 
 // scene value for one pose: min over boxes (boxes pointer and nb are wave-uniform)
 template <typename T>
-__device__ __forceinline__ T pose_distance(const Pose<T> &p, T ax, T ay, T az, const BoxRec<T> *__restrict__ boxes,
+__device__ __forceinline__ T pose_distance(const Pose<T> &pw, T ax, T ay, T az, const BoxRec<T> *__restrict__ boxes,
                                             int nb, int &arg_box)
 {
     T sep2 = Lim<T>::inf(), pen = Lim<T>::inf();
@@ -174,8 +190,12 @@ __device__ __forceinline__ T pose_distance(const Pose<T> &p, T ax, T ay, T az, c
     for (int b = 0; b < nb; ++b) {
         const BoxRec<T> bx = nxt;
         nxt = load_box_uniform(boxes, b + 1 < nb ? b + 1 : b);
+        T qx = pw.px, qy = pw.py, qc = pw.c, qs = pw.s;
+        to_box_frame(bx, qx, qy, qc, qs);
+        Pose<T> p;
+        pose_setup(p, qx, qy, pw.pz, qc, qs, ax, ay);
         PairOut<T> o;
-        pair_axes(p, ax, ay, az, bx.cx, bx.cy, bx.cz, bx.hx, bx.hy, bx.hz, o);
+        pair_axes(p, ax, ay, az, T(0), T(0), bx.cz, bx.hx, bx.hy, bx.hz, o);
         const bool xy_sep = o.gsat > T(0);
         const bool separated = xy_sep || o.gz > T(0);
         T dxy2 = T(0);
@@ -291,11 +311,34 @@ __device__ __forceinline__ float aabb_lb2(float px, float py, float pz, float ex
 
 // d(pair)/d(px,py,pz,theta[rad]) for the deciding box (mirrors the oracle's pair_grad)
 template <typename T>
-__device__ __forceinline__ void pair_grad(const Pose<T> &p, T ax, T ay, T az, const BoxRec<T> bx, T &g0, T &g1,
-                                           T &g2, T &g3)
+__device__ __forceinline__ void pair_grad_local(const Pose<T> &p, T ax, T ay, T az, T bcx, T bcy, const BoxRec<T> bx,
+                                                 T &g0, T &g1, T &g2, T &g3);
+
+// world pose (px,py,pz,c,s) against one box; `rot` (wave-uniform) = the scene holds yaw-rotated boxes
+template <typename T>
+__device__ __forceinline__ void pair_grad(T px, T py, T pz, T c, T s, T ax, T ay, T az, const BoxRec<T> bx, bool rot,
+                                           T &g0, T &g1, T &g2, T &g3)
+{
+    Pose<T> p;
+    if (rot) {
+        to_box_frame(bx, px, py, c, s);
+        pose_setup(p, px, py, pz, c, s, ax, ay);
+        T l0, l1;
+        pair_grad_local(p, ax, ay, az, T(0), T(0), bx, l0, l1, g2, g3);
+        g0 = bx.cb * l0 - bx.sb * l1;   // box frame -> world
+        g1 = bx.sb * l0 + bx.cb * l1;
+    } else {
+        pose_setup(p, px, py, pz, c, s, ax, ay);
+        pair_grad_local(p, ax, ay, az, bx.cx, bx.cy, bx, g0, g1, g2, g3);
+    }
+}
+
+template <typename T>
+__device__ __forceinline__ void pair_grad_local(const Pose<T> &p, T ax, T ay, T az, T bcx, T bcy, const BoxRec<T> bx,
+                                                 T &g0, T &g1, T &g2, T &g3)
 {
     PairOut<T> o;
-    pair_axes(p, ax, ay, az, bx.cx, bx.cy, bx.cz, bx.hx, bx.hy, bx.hz, o);
+    pair_axes(p, ax, ay, az, bcx, bcy, bx.cz, bx.hx, bx.hy, bx.hz, o);
     const T c = p.c, s = p.s;
     g0 = g1 = g2 = g3 = T(0);
     const bool xy_sep = o.gsat > T(0);
@@ -376,13 +419,19 @@ __device__ __forceinline__ void pair_grad(const Pose<T> &p, T ax, T ay, T az, co
 // ---- point model -----------------------------------------------------------------------
 template <typename T>
 __device__ __forceinline__ T point_distance(T px, T py, T pz, const BoxRec<T> *__restrict__ boxes, int nb, T radius,
-                                             int &arg_box)
+                                             bool rot, int &arg_box)
 {
     T out2 = Lim<T>::inf(), in = Lim<T>::inf();
     int iout = -1, iin = -1;
     for (int b = 0; b < nb; ++b) {
         const BoxRec<T> bx = boxes[b];
-        T qx = mp_abs(px - bx.cx) - bx.hx, qy = mp_abs(py - bx.cy) - bx.hy, qz = mp_abs(pz - bx.cz) - bx.hz;
+        T ex = px - bx.cx, ey = py - bx.cy;
+        if (rot) {
+            const T exw = ex, eyw = ey;
+            ex = mp_fma(bx.sb, eyw, bx.cb * exw);
+            ey = mp_fma(bx.cb, eyw, -(bx.sb * exw));
+        }
+        T qx = mp_abs(ex) - bx.hx, qy = mp_abs(ey) - bx.hy, qz = mp_abs(pz - bx.cz) - bx.hz;
         bool outside = qx > T(0) || qy > T(0) || qz > T(0);
         T mx = mp_max(qx, T(0)), my = mp_max(qy, T(0)), mz = mp_max(qz, T(0));
         T v = mp_fma(mz, mz, mp_fma(my, my, mx * mx));
@@ -400,9 +449,14 @@ __device__ __forceinline__ T point_distance(T px, T py, T pz, const BoxRec<T> *_
 }
 
 template <typename T>
-__device__ __forceinline__ void point_grad(T px, T py, T pz, const BoxRec<T> bx, T &g0, T &g1, T &g2)
+__device__ __forceinline__ void point_grad(T px, T py, T pz, const BoxRec<T> bx, bool rot, T &g0, T &g1, T &g2)
 {
     T ex = px - bx.cx, ey = py - bx.cy, ez = pz - bx.cz;
+    if (rot) {
+        const T exw = ex, eyw = ey;
+        ex = mp_fma(bx.sb, eyw, bx.cb * exw);
+        ey = mp_fma(bx.cb, eyw, -(bx.sb * exw));
+    }
     T qx = mp_abs(ex) - bx.hx, qy = mp_abs(ey) - bx.hy, qz = mp_abs(ez) - bx.hz;
     g0 = g1 = g2 = T(0);
     if (qx > T(0) || qy > T(0) || qz > T(0)) {
@@ -417,6 +471,11 @@ __device__ __forceinline__ void point_grad(T px, T py, T pz, const BoxRec<T> bx,
         if (qz > best) { best = qz; a = 2; }
         T sg = sgn(a == 0 ? ex : (a == 1 ? ey : ez));
         g0 = a == 0 ? sg : T(0); g1 = a == 1 ? sg : T(0); g2 = a == 2 ? sg : T(0);
+    }
+    if (rot) {   // box frame -> world
+        const T l0 = g0, l1 = g1;
+        g0 = bx.cb * l0 - bx.sb * l1;
+        g1 = bx.sb * l0 + bx.cb * l1;
     }
 }
 

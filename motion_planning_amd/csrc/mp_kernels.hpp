@@ -67,7 +67,8 @@ __host__ __device__ inline int lds_bytes_per_wave(int S, int e)
     return (b + 15) & ~15;
 }
 
-template <typename T, int MODEL, bool GRAD>
+// ROT: the scene holds yaw-rotated static boxes (a separate instantiation keeps the axis-aligned code as it was)
+template <typename T, int MODEL, bool GRAD, bool ROT>
 __global__ void __launch_bounds__(256, MP_MIN_WAVES) eval_kernel(const EvalArgs<T> a)
 {
     extern __shared__ __align__(16) unsigned char smem_raw[];
@@ -261,10 +262,15 @@ __global__ void __launch_bounds__(256, MP_MIN_WAVES) eval_kernel(const EvalArgs<
                         kk = k0 + (int)(e >> 24);
                         bb = (int)(e & 0xffffffu);
                         const int ss = a.idx_safe[kk];
-                        Pose<T> ps;
-                        pose_setup(ps, P0[ss], P1[ss], P2[ss], CC[kk], SS[kk], a.ax, a.ay);
                         const BoxRec<T> bx = boxes[bb];
-                        key = pair_key(ps, a.ax, a.ay, a.az, bx.cx, bx.cy, bx.cz, bx.hx, bx.hy, bx.hz);
+                        T qx = P0[ss], qy = P1[ss], qc = CC[kk], qs = SS[kk], bcx = bx.cx, bcy = bx.cy;
+                        if (ROT) {   // evaluate the pair in the box's own frame
+                            to_box_frame(bx, qx, qy, qc, qs);
+                            bcx = T(0); bcy = T(0);
+                        }
+                        Pose<T> ps;
+                        pose_setup(ps, qx, qy, P2[ss], qc, qs, a.ax, a.ay);
+                        key = pair_key(ps, a.ax, a.ay, a.az, bcx, bcy, bx.cz, bx.hx, bx.hy, bx.hz);
                         oldk = MINKEY[kk];
                     }
                     wave_lds_sync();
@@ -324,7 +330,7 @@ __global__ void __launch_bounds__(256, MP_MIN_WAVES) eval_kernel(const EvalArgs<
             for (int k = lane; k < Sp; k += 64) {
                 const int s = a.idx_safe[k];
                 int arg = -1;
-                const T d = point_distance(P0[s], P1[s], P2[s], boxes, nb, a.radius, arg);
+                const T d = point_distance(P0[s], P1[s], P2[s], boxes, nb, a.radius, ROT, arg);
                 Dd[k] = d;
                 ARG[k] = arg;
                 if (a.dist) a.dist[cand * a.Sp + k] = d;
@@ -500,15 +506,13 @@ __global__ void __launch_bounds__(256, MP_MIN_WAVES) eval_kernel(const EvalArgs<
                     const int s = a.idx_safe[k];
                     const BoxRec<T> bx = boxes[arg];
                     if (MODEL == 1) {
-                        Pose<T> ps;
-                        pose_setup(ps, P0[s], P1[s], P2[s], CC[k], SS[k], a.ax, a.ay);
                         T g0, g1, g2, g3;
-                        pair_grad(ps, a.ax, a.ay, a.az, bx, g0, g1, g2, g3);
+                        pair_grad(P0[s], P1[s], P2[s], CC[k], SS[k], a.ax, a.ay, a.az, bx, ROT, g0, g1, g2, g3);
                         G0[s] = gd * g0; G1[s] = gd * g1; G2[s] = gd * g2;
                         GY[s] = gd * g3 * DEG2RAD;
                     } else {
                         T g0, g1, g2;
-                        point_grad(P0[s], P1[s], P2[s], bx, g0, g1, g2);
+                        point_grad(P0[s], P1[s], P2[s], bx, ROT, g0, g1, g2);
                         G0[s] = gd * g0; G1[s] = gd * g1; G2[s] = gd * g2;
                     }
                 }
@@ -609,11 +613,11 @@ __global__ void __launch_bounds__(256, MP_MIN_WAVES) eval_kernel(const EvalArgs<
 template <typename T>
 __global__ void __launch_bounds__(256) point_sdf_kernel(long long n, const T *__restrict__ pts,
                                                          const BoxRec<T> *__restrict__ boxes, int nb, T radius,
-                                                         T *__restrict__ out)
+                                                         int has_rot, T *__restrict__ out)
 {
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
         int arg;
-        out[i] = point_distance(pts[3 * i], pts[3 * i + 1], pts[3 * i + 2], boxes, nb, radius, arg);
+        out[i] = point_distance(pts[3 * i], pts[3 * i + 1], pts[3 * i + 2], boxes, nb, radius, has_rot != 0, arg);
     }
 }
 

@@ -52,26 +52,45 @@ def goal_normal_resultant(goal_normals) -> Tuple[np.ndarray, bool]:
     return s, True
 
 
+def as_boxes8(boxes) -> np.ndarray:
+    """(B,6) axis-aligned rows or (B,8) rows -> contiguous float64 (B,8) rows
+    cx,cy,cz,hx,hy,hz,qz,qw  (qz, qw = z and w of the box's yaw-only quaternion; identity = 0, 1)."""
+    b = np.asarray(boxes, dtype=np.float64)
+    if b.size == 0:
+        return np.zeros((0, 8), dtype=np.float64)
+    b = np.atleast_2d(b)
+    if b.shape[1] == 6:
+        b = np.hstack([b, np.zeros((b.shape[0], 1)), np.ones((b.shape[0], 1))])
+    if b.shape[1] != 8:
+        raise ValueError("box rows must have 6 or 8 columns")
+    return np.ascontiguousarray(b)
+
+
 def scene_to_boxes(scene, ignore_ids: Optional[Sequence[str]] = None) -> np.ndarray:
     """SoA export of a duck-typed scene: rows (cx,cy,cz,hx,hy,hz) of every block that is
-    not ignored (geom/scene.py:88-95).  Static blocks must be axis aligned."""
+    not ignored (geom/scene.py:88-95).  If any static block is rotated about z, the rows get two
+    more columns, the z and w of its quaternion (geom/blocks.py:8-21 keeps ``quat`` as [x,y,z,w]);
+    blocks tilted out of the horizontal plane are not supported."""
     ignore = set(ignore_ids or [])
     rows: List[List[float]] = []
+    rotated = False
     for b in getattr(scene, "blocks", []):
         oid = getattr(b, "object_id", None)
         if oid is not None and oid in ignore:
             continue
         q = tuple(float(v) for v in getattr(b, "quat", (0.0, 0.0, 0.0, 1.0)))
-        if not (q[0] == 0.0 and q[1] == 0.0 and q[2] == 0.0 and abs(q[3]) == 1.0):
-            raise NotImplementedError(
-                "rotated static blocks are not supported yet (all shipped scenarios are axis aligned)"
-            )
+        if not (q[0] == 0.0 and q[1] == 0.0):
+            raise NotImplementedError("static blocks tilted about x or y are not supported (yaw-only rotations are)")
+        if abs(q[2] * q[2] + q[3] * q[3] - 1.0) > 1e-9:
+            raise ValueError("static block quaternion is not of unit length")
+        rotated = rotated or q[2] != 0.0
         sx, sy, sz = (float(v) for v in b.size)
         px, py, pz = (float(v) for v in b.position)
-        rows.append([px, py, pz, 0.5 * sx, 0.5 * sy, 0.5 * sz])
+        rows.append([px, py, pz, 0.5 * sx, 0.5 * sy, 0.5 * sz, q[2], q[3] if q[2] != 0.0 else 1.0])
     if not rows:
         return np.zeros((0, 6), dtype=np.float64)
-    return np.ascontiguousarray(np.asarray(rows, dtype=np.float64))
+    arr = np.ascontiguousarray(np.asarray(rows, dtype=np.float64))
+    return arr if rotated else np.ascontiguousarray(arr[:, :6])
 
 
 @dataclass
@@ -109,7 +128,7 @@ class PathProblem:
     goal_normal: np.ndarray
     has_goal_normal: bool
     yaw_increasing: bool
-    boxes: np.ndarray           # (B,6)
+    boxes: np.ndarray           # (B,6) axis aligned, or (B,8) with (qz, qw) of each box's yaw quaternion
     x0: np.ndarray
     sigma0: np.ndarray
     combined_4d: bool = True

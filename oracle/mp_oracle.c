@@ -176,13 +176,29 @@ typedef struct {
     real pen;     /* overlapping: max(gsat, gz) <= 0                                 */
     int separated;
     int feature;  /* separated && gsat > 0: argmin vertex test 0..7                 */
+    pose_t q;     /* the pose expressed in the box's own (yaw-rotated) frame        */
 } pair_t;
 
-static void pair_eval(const pose_t *p, const real *b /* cx,cy,cz,hx,hy,hz */, pair_t *o)
+/* Box record: cx,cy,cz, hx,hy,hz, cb,sb  (cb,sb = cos/sin of the box's own yaw; 1,0 = axis aligned).
+ * A yaw-rotated static box is handled by expressing the pair in the box frame: relative position
+ * R_b^T (p - c_b) and relative rotation theta_a - theta_b; distances are invariant.  For cb = 1,
+ * sb = 0 every expression below reduces bit-for-bit to the axis-aligned formulas. */
+#define BOX_STRIDE 8
+
+static void pair_eval(const pose_t *pw, const real *b, pair_t *o)
 {
+    const real cb = b[6], sb = b[7];
+    const real a3[3] = {pw->ax, pw->ay, pw->az};
+    real dxw = pw->px - b[0], dyw = pw->py - b[1];
+    real dx = FMA(sb, dyw, cb * dxw);
+    real dy = FMA(cb, dyw, -(sb * dxw));
+    real cr = FMA(pw->s, sb, pw->c * cb);
+    real sr = FMA(-pw->c, sb, pw->s * cb);
+    pose_setup_cs(&o->q, dx, dy, pw->pz - b[2], cr, sr, a3);
+    const pose_t *p = &o->q;
     real c = p->c, s = p->s, ac = FABS(c), as = FABS(s);
     real hbx = b[3], hby = b[4], hbz = b[5];
-    real dx = p->px - b[0], dy = p->py - b[1], dz = p->pz - b[2];
+    real dz = p->pz;
     o->dx = dx; o->dy = dy; o->dz = dz;
     o->gz = FABS(dz) - (p->az + hbz);
     o->gx = FABS(dx) - (hbx + p->ex);
@@ -234,7 +250,7 @@ static real pose_distance(const pose_t *p, const real *boxes, int nb, int *arg_b
     int isep = -1, ipen = -1;
     for (int b = 0; b < nb; ++b) {
         pair_t o;
-        pair_eval(p, boxes + 6 * (size_t)b, &o);
+        pair_eval(p, boxes + BOX_STRIDE * (size_t)b, &o);
         if (o.separated) {
             if (o.v2 < sep2) { sep2 = o.v2; isep = b; }
         } else {
@@ -247,10 +263,23 @@ static real pose_distance(const pose_t *p, const real *boxes, int nb, int *arg_b
 }
 
 /* partial derivatives of the pair distance w.r.t. (px,py,pz, theta[rad]) */
-static void pair_grad(const pose_t *p, const real *b, real g[4])
+static void pair_grad_local(const pair_t *po, const real *b, real g[4]);
+
+static void pair_grad(const pose_t *pw, const real *b, real g[4])
 {
     pair_t o;
-    pair_eval(p, b, &o);
+    pair_eval(pw, b, &o);
+    pair_grad_local(&o, b, g);
+    /* the gradient came out in the box frame: rotate its xy part back to the world */
+    const real cb = b[6], sb = b[7];
+    real gx = cb * g[0] - sb * g[1], gy = sb * g[0] + cb * g[1];
+    g[0] = gx; g[1] = gy;
+}
+
+static void pair_grad_local(const pair_t *po, const real *b, real g[4])
+{
+    const pair_t o = *po;
+    const pose_t *p = &po->q;
     real c = p->c, s = p->s;
     real hbx = b[3], hby = b[4];
     g[0] = g[1] = g[2] = g[3] = RL(0.0);
@@ -310,9 +339,10 @@ static real point_distance(real px, real py, real pz, const real *boxes, int nb,
     real out2 = INF_R, in = INF_R;
     int iout = -1, iin = -1;
     for (int b = 0; b < nb; ++b) {
-        const real *bx = boxes + 6 * (size_t)b;
-        real qx = FABS(px - bx[0]) - bx[3], qy = FABS(py - bx[1]) - bx[4],
-             qz = FABS(pz - bx[2]) - bx[5];
+        const real *bx = boxes + BOX_STRIDE * (size_t)b;
+        real exw = px - bx[0], eyw = py - bx[1];
+        real ex = FMA(bx[7], eyw, bx[6] * exw), ey = FMA(bx[6], eyw, -(bx[7] * exw));
+        real qx = FABS(ex) - bx[3], qy = FABS(ey) - bx[4], qz = FABS(pz - bx[2]) - bx[5];
         if (qx > RL(0.0) || qy > RL(0.0) || qz > RL(0.0)) {
             real mx = qx > RL(0.0) ? qx : RL(0.0), my = qy > RL(0.0) ? qy : RL(0.0),
                  mz = qz > RL(0.0) ? qz : RL(0.0);
@@ -330,7 +360,8 @@ static real point_distance(real px, real py, real pz, const real *boxes, int nb,
 
 static void point_grad(real px, real py, real pz, const real *bx, real g[3])
 {
-    real ex = px - bx[0], ey = py - bx[1], ez = pz - bx[2];
+    real exw = px - bx[0], eyw = py - bx[1], ez = pz - bx[2];
+    real ex = FMA(bx[7], eyw, bx[6] * exw), ey = FMA(bx[6], eyw, -(bx[7] * exw));
     real qx = FABS(ex) - bx[3], qy = FABS(ey) - bx[4], qz = FABS(ez) - bx[5];
     g[0] = g[1] = g[2] = RL(0.0);
     if (qx > RL(0.0) || qy > RL(0.0) || qz > RL(0.0)) {
@@ -344,6 +375,10 @@ static void point_grad(real px, real py, real pz, const real *bx, real g[3])
         if (qy > best) { best = qy; a = 1; }
         if (qz > best) { best = qz; a = 2; }
         g[a] = sgn(a == 0 ? ex : a == 1 ? ey : ez);
+    }
+    {   /* box frame -> world */
+        real gx = bx[6] * g[0] - bx[7] * g[1], gy = bx[7] * g[0] + bx[6] * g[1];
+        g[0] = gx; g[1] = gy;
     }
 }
 
@@ -499,7 +534,7 @@ static void eval_one(const mp_config *cf, const mp_task *tk, const real *boxes, 
     /* --- clearance profile d_safe (:538-545, _path_distances :148-186) --- */
     int Sp = cf->n_safe;
     const int nb = tk->box_count;
-    const real *bx = boxes + 6 * (size_t)tk->box_begin;
+    const real *bx = boxes + BOX_STRIDE * (size_t)tk->box_begin;
     real a3[3] = {(real)cf->half_extents[0], (real)cf->half_extents[1], (real)cf->half_extents[2]};
     for (int k = 0; k < Sp; ++k) {
         int s = cf->idx_safe[k];
@@ -679,7 +714,7 @@ static void eval_one(const mp_config *cf, const mp_task *tk, const real *boxes, 
         for (int k = 0; k < Sp; ++k) {
             if (gd[k] == RL(0.0) || w->arg[k] < 0) continue;
             int s = cf->idx_safe[k];
-            const real *bb = bx + 6 * (size_t)w->arg[k];
+            const real *bb = bx + BOX_STRIDE * (size_t)w->arg[k];
             if (cf->model == MP_MODEL_BOX) {
                 pose_t ps;
                 real g[4];
@@ -713,7 +748,7 @@ static void eval_one(const mp_config *cf, const mp_task *tk, const real *boxes, 
 }
 
 /* ------------------------------------------------------------------------------
- * Exported entry points (ctypes).  boxes6: [n_boxes x 6] = cx,cy,cz,hx,hy,hz doubles.
+ * Exported entry points (ctypes).  boxes8: [n_boxes x 8] = cx,cy,cz,hx,hy,hz,cos,sin doubles.
  * cfg->basis / basis_yaw / t_sched must be non-NULL.
  * ---------------------------------------------------------------------------- */
 static real *to_real(const double *src, size_t n)
@@ -725,14 +760,14 @@ static real *to_real(const double *src, size_t n)
 
 int ORC_NAME(orc_eval)(const mp_config *cf, const mp_task *tasks, int32_t n_tasks,
                        int64_t cands_per_task, const int32_t *task_of, int32_t n_boxes,
-                       const double *boxes6, int64_t n, const real *X, real *cost, real *terms,
+                       const double *boxes8, int64_t n, const real *X, real *cost, real *terms,
                        real *grad, real *min_clear, uint8_t *flags, real *dist)
 {
     if (!cf || !tasks || !cf->basis || !cf->basis_yaw || !cf->t_sched) return MP_E_ARG;
     if (cf->n_samples > MP_MAX_SAMPLES || cf->n_ctrl > MP_MAX_CTRL) return MP_E_ARG;
     const int S = cf->n_samples, C = cf->n_ctrl, Cy = cf->n_yaw_ctrl;
     const int D = 3 * cf->n_free + cf->n_yaw_free;
-    real *bx = to_real(boxes6, 6 * (size_t)n_boxes);
+    real *bx = to_real(boxes8, BOX_STRIDE * (size_t)n_boxes);
     real *M = to_real(cf->basis, (size_t)S * C);
     real *My = to_real(cf->basis_yaw, (size_t)S * Cy);
     real *ts = to_real(cf->t_sched, (size_t)S);
@@ -750,20 +785,20 @@ int ORC_NAME(orc_eval)(const mp_config *cf, const mp_task *tasks, int32_t n_task
     return rc;
 }
 
-int ORC_NAME(orc_point_sdf)(int32_t n_boxes, const double *boxes6, double radius, int64_t n,
+int ORC_NAME(orc_point_sdf)(int32_t n_boxes, const double *boxes8, double radius, int64_t n,
                             const real *pts, real *out)
 {
-    real *bx = to_real(boxes6, 6 * (size_t)n_boxes);
+    real *bx = to_real(boxes8, BOX_STRIDE * (size_t)n_boxes);
     for (int64_t i = 0; i < n; ++i)
         out[i] = point_distance(pts[3 * i], pts[3 * i + 1], pts[3 * i + 2], bx, n_boxes, (real)radius, NULL);
     free(bx);
     return MP_OK;
 }
 
-int ORC_NAME(orc_box_sdf)(int32_t n_boxes, const double *boxes6, const double size[3], int64_t n,
+int ORC_NAME(orc_box_sdf)(int32_t n_boxes, const double *boxes8, const double size[3], int64_t n,
                           const real *pos, const real *yaw_deg, real *out)
 {
-    real *bx = to_real(boxes6, 6 * (size_t)n_boxes);
+    real *bx = to_real(boxes8, BOX_STRIDE * (size_t)n_boxes);
     real a3[3] = {(real)(0.5 * size[0]), (real)(0.5 * size[1]), (real)(0.5 * size[2])};
     for (int64_t i = 0; i < n; ++i) {
         pose_t ps;
@@ -776,10 +811,10 @@ int ORC_NAME(orc_box_sdf)(int32_t n_boxes, const double *boxes6, const double si
 
 /* same query with the rotation given as (cos, sin): used by the golden generator's stub
  * scene, which receives the reference's own quaternion (scene.py:70-76). */
-int ORC_NAME(orc_box_sdf_cs)(int32_t n_boxes, const double *boxes6, const double size[3], int64_t n,
+int ORC_NAME(orc_box_sdf_cs)(int32_t n_boxes, const double *boxes8, const double size[3], int64_t n,
                              const real *pos, const real *c, const real *s, real *out)
 {
-    real *bx = to_real(boxes6, 6 * (size_t)n_boxes);
+    real *bx = to_real(boxes8, BOX_STRIDE * (size_t)n_boxes);
     real a3[3] = {(real)(0.5 * size[0]), (real)(0.5 * size[1]), (real)(0.5 * size[2])};
     for (int64_t i = 0; i < n; ++i) {
         pose_t ps;

@@ -78,7 +78,7 @@ def evaluate(
         tasks[i] = p.task_struct(box_begin=off, box_count=p.boxes.shape[0])
         boxes.append(p.boxes)
         off += p.boxes.shape[0]
-    boxes6 = np.ascontiguousarray(np.vstack(boxes) if boxes else np.zeros((0, 6)), dtype=np.float64)
+    boxes6 = np.ascontiguousarray(np.vstack([as_boxes8(b) for b in boxes])) if boxes else np.zeros((0, 8))
     cost = np.empty(n, dtype=dt)
     terms = np.empty((n, abi.MP_NTERMS), dtype=dt)
     grad = np.empty((n, D), dtype=dt) if want_grad else None
@@ -96,9 +96,29 @@ def evaluate(
     return {"cost": cost, "terms": terms, "grad": grad, "min_clear": minc, "flags": flags, "dist": dist}
 
 
+def as_boxes8(boxes) -> np.ndarray:
+    """Box rows for the C oracle.  Input: (B,6) cx,cy,cz,hx,hy,hz (axis aligned) or (B,8) with the z and w
+    components of the box's yaw-only quaternion appended (the host-side row format of
+    motion_planning_amd.problem.scene_to_boxes).  Output: contiguous float64 (B,8) with (cos, sin) of the
+    box yaw in the last two columns, composed like the reference's quat_to_rot (geom/utils.py:3-14):
+    R00 = 1 - 2 zz, R10 = 2 wz."""
+    b = np.asarray(boxes, dtype=np.float64)
+    if b.size == 0:
+        return np.zeros((0, 8))
+    b = np.atleast_2d(b)
+    if b.shape[1] == 6:
+        b = np.hstack([b, np.zeros((b.shape[0], 1)), np.ones((b.shape[0], 1))])
+    assert b.shape[1] == 8
+    out = b.copy()
+    z, w = b[:, 6], b[:, 7]
+    out[:, 6] = 1.0 - 2.0 * (z * z)
+    out[:, 7] = 2.0 * (w * z)
+    return np.ascontiguousarray(out)
+
+
 def point_sdf(boxes6: np.ndarray, pts: np.ndarray, radius: float = 1e-6, dtype=np.float64) -> np.ndarray:
     dt, sfx = _real(dtype)
-    boxes6 = np.ascontiguousarray(boxes6, dtype=np.float64).reshape(-1, 6)
+    boxes6 = as_boxes8(boxes6)
     pts = np.ascontiguousarray(pts, dtype=dt).reshape(-1, 3)
     out = np.empty(pts.shape[0], dtype=dt)
     fn = getattr(lib(), f"orc_point_sdf_{sfx}")
@@ -110,7 +130,7 @@ def point_sdf(boxes6: np.ndarray, pts: np.ndarray, radius: float = 1e-6, dtype=n
 
 def box_sdf(boxes6: np.ndarray, size, pos: np.ndarray, yaw_deg: np.ndarray, dtype=np.float64) -> np.ndarray:
     dt, sfx = _real(dtype)
-    boxes6 = np.ascontiguousarray(boxes6, dtype=np.float64).reshape(-1, 6)
+    boxes6 = as_boxes8(boxes6)
     pos = np.ascontiguousarray(pos, dtype=dt).reshape(-1, 3)
     yaw = np.ascontiguousarray(yaw_deg, dtype=dt).reshape(-1)
     assert yaw.shape[0] == pos.shape[0]
@@ -125,7 +145,7 @@ def box_sdf(boxes6: np.ndarray, size, pos: np.ndarray, yaw_deg: np.ndarray, dtyp
 
 def box_sdf_cs(boxes6: np.ndarray, size, pos: np.ndarray, c: np.ndarray, s: np.ndarray) -> np.ndarray:
     """Box query with the rotation given as (cos, sin) — fp64 only."""
-    boxes6 = np.ascontiguousarray(boxes6, dtype=np.float64).reshape(-1, 6)
+    boxes6 = as_boxes8(boxes6)
     pos = np.ascontiguousarray(pos, dtype=np.float64).reshape(-1, 3)
     c = np.ascontiguousarray(c, dtype=np.float64).reshape(-1)
     s = np.ascontiguousarray(s, dtype=np.float64).reshape(-1)

@@ -55,3 +55,19 @@ def rel_err(got, ref, floor=1e-12):
     with np.errstate(invalid="ignore"):
         e = np.abs(got - ref) / np.maximum(np.abs(ref), floor)
     return np.where(np.isfinite(e), e, 0.0)
+
+
+def with_rotated_statics(prob, seed=0, keep_first=True):
+    """Same problem with every static box (but the first: the table) turned about z by a random angle:
+    rows grow to 8 columns, (z, w) of the yaw-only quaternion appended."""
+    import dataclasses
+
+    rng = np.random.default_rng(seed)
+    b = np.asarray(prob.boxes, dtype=float)[:, :6]
+    ang = np.radians(rng.uniform(-180.0, 180.0, b.shape[0]))
+    if keep_first and b.shape[0]:
+        ang[0] = 0.0
+    rows = np.hstack([b, np.sin(0.5 * ang)[:, None], np.cos(0.5 * ang)[:, None]])
+    rows[ang == 0.0, 6] = 0.0
+    rows[ang == 0.0, 7] = 1.0
+    return dataclasses.replace(prob, boxes=np.ascontiguousarray(rows))

@@ -107,3 +107,69 @@ def test_scene_value_is_min_over_boxes_and_ignores_nothing(oracle_lib):
     pf = oracle_lib.point_sdf(boxes, pos)
     pe = np.stack([oracle_lib.point_sdf(boxes[i:i + 1], pos) for i in range(7)])
     np.testing.assert_array_equal(pf, pe.min(axis=0))
+
+
+def _rotz(yaw_deg):
+    c, s = np.cos(np.radians(yaw_deg)), np.sin(np.radians(yaw_deg))
+    return np.array([[c, -s, 0], [s, c, 0], [0, 0, 1.0]])
+
+
+def _box8(cb, hb, yaw_b):
+    # host row format: centre, half extents, (z, w) of the yaw-only quaternion
+    return np.concatenate([cb, hb, [np.sin(np.radians(yaw_b) / 2), np.cos(np.radians(yaw_b) / 2)]])[None, :]
+
+
+def test_rotated_static_box_against_independent_solver(oracle_lib):
+    """Static boxes with a yaw of their own (8-column rows): same definition, evaluated in the box frame."""
+    rng = np.random.default_rng(15)
+    n_sep = n_pen = 0
+    for _ in range(400):
+        hb = rng.uniform(0.05, 0.6, 3)
+        cb = rng.uniform(-0.5, 0.5, 3)
+        ha = rng.uniform(0.05, 0.5, 3)
+        pa = cb + rng.uniform(-1.5, 1.5, 3)
+        yaw = rng.choice([0.0, 90.0, rng.uniform(-180, 180)])
+        yaw_b = rng.choice([0.0, 30.0, -90.0, rng.uniform(-180, 180)])
+        Ra, Rb = _rotz(yaw), _rotz(yaw_b)
+        got = float(oracle_lib.box_sdf(_box8(cb, hb, yaw_b), 2 * ha, pa[None, :], np.array([yaw]))[0])
+        # 15-axis SAT with both orientations
+        axes = [Ra[:, i] for i in range(3)] + [Rb[:, i] for i in range(3)]
+        axes += [np.cross(Ra[:, i], Rb[:, j]) for i in range(3) for j in range(3)]
+        depth = -np.inf
+        for ax in axes:
+            nrm = np.linalg.norm(ax)
+            if nrm < 1e-9:
+                continue
+            ax = ax / nrm
+            depth = max(depth, abs((pa - cb) @ ax) - np.sum(np.abs(Ra.T @ ax) * ha) - np.sum(np.abs(Rb.T @ ax) * hb))
+        if depth > 1e-6:
+            A = np.hstack([Ra, -Rb])
+            res = lsq_linear(A, cb - pa, bounds=(np.concatenate([-ha, -hb]), np.concatenate([ha, hb])), tol=1e-14, max_iter=500)
+            assert got == pytest.approx(float(np.linalg.norm(A @ res.x - (cb - pa))), abs=2e-7), (pa, ha, yaw, cb, hb, yaw_b)
+            n_sep += 1
+        elif depth < -1e-6:
+            assert got == pytest.approx(depth, abs=1e-12)
+            n_pen += 1
+    assert n_sep > 100 and n_pen > 20
+
+
+def test_rotated_static_is_frame_invariant(oracle_lib):
+    """Rotating the whole pair about the static box's centre does not change the distance (to rounding),
+    and an 8-column row with (1, 0) equals the 6-column row bit for bit."""
+    rng = np.random.default_rng(16)
+    boxes6 = np.hstack([rng.uniform(-1, 1, (5, 3)), rng.uniform(0.05, 0.3, (5, 3))])
+    pos = rng.uniform(-2, 2, (64, 3))
+    yaw = rng.uniform(-180, 180, 64)
+    size = (0.3, 0.2, 0.1)
+    b8 = np.hstack([boxes6, np.zeros((5, 1)), np.ones((5, 1))])   # identity quaternion: z = 0, w = 1
+    np.testing.assert_array_equal(oracle_lib.box_sdf(b8, size, pos, yaw), oracle_lib.box_sdf(boxes6, size, pos, yaw))
+    np.testing.assert_array_equal(oracle_lib.point_sdf(b8, pos), oracle_lib.point_sdf(boxes6, pos))
+    for phi in (17.0, -123.0):
+        R = _rotz(phi)
+        one = boxes6[:1]
+        c0 = one[0, :3]
+        pos_r = (pos - c0) @ R.T + c0
+        rot = _box8(one[0, :3], one[0, 3:6], phi)
+        np.testing.assert_allclose(oracle_lib.box_sdf(rot, size, pos_r, yaw + phi), oracle_lib.box_sdf(one, size, pos, yaw),
+                                   rtol=0, atol=1e-13)
+        np.testing.assert_allclose(oracle_lib.point_sdf(rot, pos_r), oracle_lib.point_sdf(one, pos), rtol=0, atol=1e-13)

@@ -404,3 +404,73 @@ def test_plain_c_caller(native, oracle_lib):
     np.testing.assert_array_equal(got[:, 1], ref["min_clear"])
     np.testing.assert_array_equal(got[:, 2].astype(np.uint8), ref["flags"])
     np.testing.assert_allclose(got[:, 3:], ref["grad"], rtol=1e-9, atol=1e-9)
+
+
+# ---- static boxes with a yaw of their own --------------------------------------------------
+@pytest.mark.parametrize("name", ["base_between", "synth50_seed0", "front_point", "vias_box_sub5", "front_vias5_s256"])
+def test_rotated_static_boxes_match_oracle(name, native, oracle_lib):
+    case = next(c for c in CASES if c["name"] == name)
+    prob = H.with_rotated_statics(H.problem_for_case(case), seed=21)
+    rng = np.random.default_rng(22)
+    X = np.vstack([G3[f"{name}__X"], prob.x0 + prob.sigma0 * rng.normal(size=(200, prob.dim))])
+    for dt in (np.float64, np.float32):
+        ctx = native.Context(0, dt)
+        ctx.set_problem(prob)
+        Xd = X.astype(dt)
+        out = ctx.eval(Xd, want_grad=True, want_dist=True)
+        ref = oracle_lib.evaluate(prob, Xd, dtype=dt)
+        _compare(out, ref, dt)
+        out2 = ctx.eval(Xd, want_grad=False, want_terms=False)
+        np.testing.assert_array_equal(out2["flags"], ref["flags"])
+        np.testing.assert_array_equal(out2["min_clear"], ref["min_clear"])
+        ctx.close()
+
+
+def test_rotated_static_boxes_large_scene_and_queries(native, oracle_lib):
+    """2,000 rotated boxes (grouped, Morton-sorted bound tables over world AABBs) and the stand-alone queries."""
+    import dataclasses
+
+    from motion_planning_amd.synthetic import synthetic_candidates, synthetic_problem
+
+    prob = synthetic_problem(native.build_basis, 2000, 64, seed=5)
+    prob = H.with_rotated_statics(prob, seed=6)
+    X = synthetic_candidates(prob, 256, seed=7)
+    ctx = native.Context(0)
+    ctx.set_problem(prob)
+    out = ctx.eval(X, want_grad=True, want_dist=True)
+    ref = oracle_lib.evaluate(prob, X)
+    _compare(out, ref, np.float64)
+    rng = np.random.default_rng(9)
+    pos = rng.uniform(-2, 2, (3000, 3))
+    yaw = rng.uniform(-400, 400, 3000)
+    for dt in (np.float64, np.float32):
+        c2 = native.Context(0, dt)
+        c2.set_scene(prob.boxes[:60])
+        np.testing.assert_array_equal(c2.box_sdf((0.9, 0.6, 0.6), pos, yaw), oracle_lib.box_sdf(prob.boxes[:60], (0.9, 0.6, 0.6), pos, yaw, dtype=dt))
+        np.testing.assert_array_equal(c2.point_sdf(pos), oracle_lib.point_sdf(prob.boxes[:60], pos, dtype=dt))
+        c2.close()
+    # a mixed batch: one task axis aligned, one rotated, in the same launch
+    plain = dataclasses.replace(prob, boxes=np.ascontiguousarray(prob.boxes[:50, :6]))
+    rot = dataclasses.replace(prob, boxes=np.ascontiguousarray(prob.boxes[:50]))
+    ctx.set_problem([plain, rot])
+    ctx.set_cands_per_task(128)
+    out = ctx.eval(X, want_grad=True, want_dist=True)
+    ref = oracle_lib.evaluate([plain, rot], X, cands_per_task=128)
+    _compare(out, ref, np.float64)
+    only_plain = oracle_lib.evaluate(plain, X[:128])
+    np.testing.assert_array_equal(out["dist"][:128], only_plain["dist"])   # the box-frame path with (1, 0) is the aligned path
+    ctx.close()
+
+
+def test_tilted_static_box_is_refused(native):
+    import ctypes as C
+
+    ctx = native.Context(0)
+    one = np.ones(1)
+    q = np.array([[np.sin(0.2), 0.0, 0.0, np.cos(0.2)]])
+    p = lambda a: a.ctypes.data_as(C.c_void_p)
+    rc = ctx.lib.mp_set_scene(ctx._h, 1, p(one), p(one), p(one), p(one), p(one), p(one), p(q))
+    assert rc == abi.MP_E_UNSUPPORTED
+    q = np.array([[0.0, 0.0, 0.5, 0.5]])
+    assert ctx.lib.mp_set_scene(ctx._h, 1, p(one), p(one), p(one), p(one), p(one), p(one), p(q)) == abi.MP_E_ARG
+    ctx.close()

@@ -38,3 +38,24 @@ def test_gradient_matches_central_differences(name, oracle_lib):
         assert np.abs(g - f1).max() <= 2e-5 * scale, (name, i, g, f1)
         good += 1
     assert good >= (X.shape[0] - 1) // 2, f"{name}: too few smooth points ({good}/{X.shape[0]})"
+
+
+@pytest.mark.parametrize("name", ["base_between", "synth50_seed0", "front_point", "vias_box_sub5"])
+def test_gradient_with_rotated_static_boxes(name, oracle_lib):
+    """Static boxes with a yaw of their own: the pair gradient is computed in the box frame and rotated back."""
+    prob = H.with_rotated_statics(H.problem_for_case(CASES[name]), seed=3)
+    assert prob.boxes.shape[1] == 8
+    X = H.load_g3()[f"{name}__X"]
+    out = oracle_lib.evaluate(prob, X)
+    base = oracle_lib.evaluate(H.problem_for_case(CASES[name]), X)
+    assert not np.array_equal(out["dist"], base["dist"])     # the rotation really changed the scene
+    good = 0
+    for i in range(1, X.shape[0]):
+        g = out["grad"][i]
+        f1, f2 = _fd(oracle_lib, prob, X[i], 1e-6), _fd(oracle_lib, prob, X[i], 2e-6)
+        scale = np.abs(g).max() + 1e-9
+        if np.abs(f1 - f2).max() > 1e-4 * scale:
+            continue
+        assert np.abs(g - f1).max() <= 2e-5 * scale, (name, i, g, f1)
+        good += 1
+    assert good >= (X.shape[0] - 1) // 3, f"{name}: too few smooth points ({good}/{X.shape[0]})"

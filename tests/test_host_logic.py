@@ -144,9 +144,20 @@ def test_with_vias_validation(oracle_lib):
         so.build_scalar_bspline(np.zeros(1))
 
 
-def test_rotated_static_blocks_are_refused():
-    from motion_planning_amd.blocks import Block
-    from motion_planning_amd.problem import scene_to_boxes
+def test_static_block_rotations():
+    """Yaw-rotated static blocks export 8-column rows (z, w of the quaternion); tilted ones are refused."""
+    import math
 
+    from motion_planning_amd.blocks import Block
+    from motion_planning_amd.problem import as_boxes8, scene_to_boxes
+
+    z, w = math.sin(math.pi / 8), math.cos(math.pi / 8)
+    rows = scene_to_boxes(BoxList([Block((1, 1, 1), (0, 0, 0)), Block((1, 2, 1), (3, 0, 0), quat=(0.0, 0.0, z, w))]))
+    assert rows.shape == (2, 8)
+    np.testing.assert_array_equal(rows[:, 6:], [[0.0, 1.0], [z, w]])
+    assert scene_to_boxes(BoxList([Block((1, 1, 1), (0, 0, 0), quat=(0.0, 0.0, 0.0, -1.0))])).shape == (1, 6)
+    np.testing.assert_array_equal(as_boxes8(np.zeros((2, 6)))[:, 6:], [[0.0, 1.0]] * 2)
     with pytest.raises(NotImplementedError):
-        scene_to_boxes(BoxList([Block((1, 1, 1), (0, 0, 0), quat=(0.0, 0.0, 0.3826834, 0.9238795))]))
+        scene_to_boxes(BoxList([Block((1, 1, 1), (0, 0, 0), quat=(0.3826834323650898, 0.0, 0.0, 0.9238795325112867))]))
+    with pytest.raises(ValueError):
+        scene_to_boxes(BoxList([Block((1, 1, 1), (0, 0, 0), quat=(0.0, 0.0, 0.5, 0.5))]))
