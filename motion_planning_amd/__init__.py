@@ -4,5 +4,5 @@ include/mp_api.h); this package is the Python host that mirrors the reference's 
 surface.  Importing the package does not load the native library; the first call that
 needs it does, and fails loudly when it is missing."""
 
-__all__ = ["spline_opt", "scene", "blocks", "utils", "problem", "batch", "scenarios"]
+__all__ = ["spline_opt", "scene", "blocks", "utils", "problem", "batch", "scenarios", "planning"]
 __version__ = "0.1.0"

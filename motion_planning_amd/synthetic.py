@@ -146,3 +146,67 @@ def wall_scenario_problems(basis_fn, n_scenarios: int, seed: int = 2, n_samples:
         out.append(build_path_problem(BoxList(blocks), start, goal, cached_basis, moving_block_size=_BLOCK,
                                       start_yaw_deg=0.0, goal_yaw_deg=0.0, goal_approach_normals=normals, **cfg))
     return out
+
+
+# ---- the four deterministic construction steps (example/generate_scenarios.py:153-264) ------------------
+def _r6(v: float) -> float:
+    out = round(float(v), 6)
+    return 0.0 if abs(out) < 1e-12 else out
+
+
+def _supported_from_below(blocks, goal, moving_size) -> bool:
+    """A block top lies directly under the moving block's bottom face at the goal (:94-117)."""
+    bottom = goal[2] - 0.5 * moving_size[2]
+    gaps = [abs(b["position"][2] + 0.5 * b["size"][2] - bottom) for b in blocks
+            if abs(goal[0] - b["position"][0]) <= 0.5 * b["size"][0] + 1e-9
+            and abs(goal[1] - b["position"][1]) <= 0.5 * b["size"][1] + 1e-9]
+    return bool(gaps) and min(gaps) <= 1e-6
+
+
+def _placement_step(blocks, goal_cfg, goal, contact_normals, fallback_approach=(0.0, -1.0, 0.0)):
+    """moving_block entry of one step: contact normals (+ the support normal if it is new, :120-133),
+    approach = minus their normalised sum (:74-85), start = goal - 1.2 approach lifted above the scene (:144-150)."""
+    normals = [np.asarray(n, dtype=float) / max(np.linalg.norm(n), 1e-300) for n in contact_normals]
+    up = np.array([0.0, 0.0, 1.0])
+    if _supported_from_below(blocks, goal, _BLOCK) and all(abs(float(up @ n)) < 0.999 for n in normals):
+        normals.append(up)
+    total = np.sum(normals, axis=0)
+    nrm = float(np.linalg.norm(total))
+    if nrm < 1e-12:
+        approach = np.asarray(fallback_approach, dtype=float)
+        approach = approach / np.linalg.norm(approach)
+    else:
+        approach = -(total / nrm)
+        approach = approach / np.linalg.norm(approach)
+    start = (goal[0] - 1.2 * approach[0], goal[1] - 1.2 * approach[1], max(goal[2] + 0.9, 1.25))
+    return {
+        "size": list(_BLOCK),
+        "start": [_r6(v) for v in start],
+        "start_yaw_deg": 0.0,
+        "goal_yaw_deg": 0.0,
+        "goal": goal_cfg,
+        "goal_normals": [[_r6(v) for v in n] for n in normals],
+        "approach_direction": [_r6(v) for v in approach],
+    }
+
+
+def generate_step_scenarios() -> dict:
+    """The payload of ``example/generated_scenarios.yaml``: first block on the ground, second in front of it,
+    third on top, fourth between two blocks — all on the block-size grid."""
+    gx, gy, gz = _BLOCK
+    ground_z = _TABLE_TOP + 0.5 * gz
+    table = {"id": "table", "size": [4.0, 4.0, 0.1], "position": [0.0, 0.0, 0.05]}
+    blk = lambda oid, c: {"id": oid, "size": list(_BLOCK), "position": [_r6(v) for v in c]}
+    face = lambda base, f: {"type": "face", "base": base, "face": f, "gap": 0.0, "tangential_offset": [0.0, 0.0], "size": list(_BLOCK)}
+    first, front = (0.0, 0.0, ground_z), (gx, 0.0, ground_z)
+    steps = {}
+    b = [table]
+    steps["step_01_first_on_ground"] = {"blocks": b, "moving_block": _placement_step(b, face("table", "top"), first, [(0.0, 0.0, 1.0)])}
+    b = [table, blk("block_1", first)]
+    steps["step_02_second_in_front"] = {"blocks": b, "moving_block": _placement_step(b, face("block_1", "front"), front, [(1.0, 0.0, 0.0)])}
+    b = [table, blk("block_1", first), blk("block_2", front)]
+    steps["step_03_third_on_top"] = {"blocks": b, "moving_block": _placement_step(b, face("block_2", "top"), (gx, 0.0, ground_z + gz), [(0.0, 0.0, 1.0)])}
+    b = [table, blk("left_block", (-gx, 0.0, ground_z)), blk("right_block", (gx, 0.0, ground_z))]
+    between = {"type": "between", "ids": ["left_block", "right_block"], "position": [None, None, _r6(ground_z)]}
+    steps["step_04_between_two_blocks"] = {"blocks": b, "moving_block": _placement_step(b, between, first, [(1.0, 0.0, 0.0), (-1.0, 0.0, 0.0)])}
+    return {"defaults": {"base_size": list(_BLOCK)}, "scenarios": steps}

@@ -112,3 +112,43 @@ def test_scene_ids_and_stacking():
     blk = s.get_block("b")
     assert blk.contains((3.5, 1.0, 1.0)) and not blk.contains((3.51, 0, 0.5))
     assert blk.vertices_world().shape == (8, 3)
+
+
+def test_step_scenario_generator_reproduces_the_reference_data_file():
+    """generate_step_scenarios() == the parsed example/generated_scenarios.yaml (golden: generated_payload.json),
+    and the placement helper follows the per-direction conventions of geom/planning.py:47-87."""
+    import json
+    from pathlib import Path
+
+    from motion_planning_amd.blocks import Block
+    from motion_planning_amd.planning import goal_and_via_for_placement
+    from motion_planning_amd.synthetic import generate_step_scenarios
+
+    gold = json.loads((Path(__file__).parent / "golden" / "generated_payload.json").read_text())
+    assert generate_step_scenarios() == gold
+
+    class One:
+        def __init__(self, b):
+            self.b = b
+
+        def get_block(self, _):
+            return self.b
+
+    blk = One(Block((0.9, 0.6, 0.4), (1.0, 2.0, 3.0)))
+    kw = dict(gap=0.01, lateral_offset=(0.1, 0.2), interlock_x=0.05)
+    # values derived by hand from the reference's formulas (the module itself needs python-fcl to import)
+    want = {"front": ((1.1, 2.61, 3.2), (1.1, 2.66, 3.45)), "back": ((1.1, 2.0, 2.29), (1.1, 2.0, 2.49)),
+            "left": ((1.91, 2.1, 3.2), (1.96, 2.1, 3.45)), "right": ((0.09, 2.1, 3.2), (0.04, 2.1, 3.45)),
+            "top": ((1.15, 2.2, 3.21), (1.15, 2.2, 3.51))}
+    for d, (g, v) in want.items():
+        goal, via = goal_and_via_for_placement(blk, 0, d.upper() if d == "top" else d, **kw)
+        np.testing.assert_allclose(goal, g, atol=1e-12)
+        np.testing.assert_allclose(via, v, atol=1e-12)
+    # a block turned by 90 deg about z: local x -> world y
+    h = np.sqrt(0.5)
+    turned = One(Block((0.9, 0.6, 0.4), (0.0, 0.0, 0.0), quat=(0.0, 0.0, h, h)))
+    goal, via = goal_and_via_for_placement(turned, 0, "left", gap=0.0, via_shift_along_normal=0.0, via_offset_local=(0.1, 0.0, 0.0))
+    np.testing.assert_allclose(goal, (0.0, 0.9, 0.0), atol=1e-12)
+    np.testing.assert_allclose(via, (0.0, 1.0, 0.0), atol=1e-12)
+    with pytest.raises(ValueError):
+        goal_and_via_for_placement(blk, 0, "under")

@@ -327,8 +327,18 @@ def gen_g5(ref, scenarios):
     (OUT / "g5_solve.json").write_text(json.dumps(runs, indent=1))
 
 
+def gen_payload():
+    """The parsed content of the reference's example/generated_scenarios.yaml (a data file, the output of its
+    generate_scenarios.py): pins motion_planning_amd.synthetic.generate_step_scenarios."""
+    payload = yaml.safe_load((REF / "example" / "generated_scenarios.yaml").read_text())
+    (OUT / "generated_payload.json").write_text(json.dumps(payload, indent=1))
+
+
 def main():
     OUT.mkdir(parents=True, exist_ok=True)
+    if "--payload-only" in sys.argv:
+        gen_payload()
+        return
     ref = load_ref()
     rng = np.random.default_rng(20260220)
     scenarios = resolve_yaml_scenarios()
@@ -340,6 +350,7 @@ def main():
     gen_g3(ref, rng, scenarios)
     gen_g4(ref, rng)
     gen_g5(ref, scenarios)
+    gen_payload()
     (OUT / "META.json").write_text(json.dumps(meta, indent=1))
     print("wrote", sorted(p.name for p in OUT.iterdir()))
 
