@@ -8,6 +8,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -53,6 +54,9 @@ struct mp_ctx {
 
     // staging for MP_MEM_HOST calls
     DevBuf s_X, s_taskof, s_cost, s_terms, s_grad, s_minc, s_flags, s_dist, s_aux0, s_aux1;
+    DevBuf s_pre_d, s_pre_arg;    // split mode: clearance profile + deciding box of every (candidate, sample)
+    int max_task_boxes = 0;
+    int split_mode = -1;          // -1 automatic, 0 never, 1 always (MP_SPLIT_CLEARANCE, tuning aid)
 
     // device-resident CEM
     DevBuf c_X, c_vals, c_minc, c_flags, c_mu, c_sigma, c_bestx, c_bestval, c_prev, c_bminc, c_bflags, c_done, c_nit,
@@ -319,8 +323,19 @@ template <typename T> int upload_problem(mp_ctx *ctx, const mp_task *tasks)
                     g.pad0 = as_float(k);   // first sorted index, relative to sbox_begin
                     g.pad1 = as_float(m);
                     gr.push_back(g);
+                    // representative: the member whose centre is nearest to the centre of the group's AABB
+                    int best = 0;
+                    float bd = INFINITY;
+                    for (int q = 0; q < m; ++q) {
+                        const mp::BoxRec32 &r = sb[(size_t)sb0 + k + q];
+                        const float d2 = (r.cx - g.cx) * (r.cx - g.cx) + (r.cy - g.cy) * (r.cy - g.cy) + (r.cz - g.cz) * (r.cz - g.cz);
+                        if (d2 < bd) { bd = d2; best = q; }
+                    }
+                    mp::BoxRec32 rep{};
+                    if (m > 0) { rep.cx = sb[(size_t)sb0 + k + best].cx; rep.cy = sb[(size_t)sb0 + k + best].cy; rep.cz = sb[(size_t)sb0 + k + best].cz; }
+                    gr.push_back(rep);
                 }
-                done.push_back({b0, cnt, sb0, g0, (int)gr.size() - g0});
+                done.push_back({b0, cnt, sb0, g0 / 2, ((int)gr.size() - g0) / 2});
                 hit = &done.back();
             }
             dt[i].sbox_begin = (*hit)[2];
@@ -337,16 +352,23 @@ template <typename T> int upload_problem(mp_ctx *ctx, const mp_task *tasks)
     return MP_OK;
 }
 
-template <typename T, int MODEL, bool GRAD, bool ROT>
-int launch_eval_r(mp_ctx *ctx, const mp::EvalArgs<T> &args, int wpb, int blocks, size_t lds_bytes)
+template <typename T, int MODEL, bool GRAD, bool ROT, bool PRE>
+int launch_eval_p(mp_ctx *ctx, const mp::EvalArgs<T> &args, int wpb, int blocks, size_t lds_bytes)
 {
-    auto kern = mp::eval_kernel<T, MODEL, GRAD, ROT>;
+    auto kern = mp::eval_kernel<T, MODEL, GRAD, ROT, PRE>;
     if (lds_bytes > 65536)
         HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                          (int)lds_bytes));
     hipLaunchKernelGGL(kern, dim3(blocks), dim3(64 * wpb), lds_bytes, ctx->stream, args);
     HIP_TRY(ctx, hipGetLastError());
     return MP_OK;
+}
+
+template <typename T, int MODEL, bool GRAD, bool ROT>
+int launch_eval_r(mp_ctx *ctx, const mp::EvalArgs<T> &args, int wpb, int blocks, size_t lds_bytes)
+{
+    if (MODEL == 1 && args.pre_d) return launch_eval_p<T, MODEL, GRAD, ROT, MODEL == 1>(ctx, args, wpb, blocks, lds_bytes);
+    return launch_eval_p<T, MODEL, GRAD, ROT, false>(ctx, args, wpb, blocks, lds_bytes);
 }
 
 template <typename T, int MODEL, bool GRAD>
@@ -392,6 +414,27 @@ int launch_eval(mp_ctx *ctx, long long n, const void *X, const int32_t *task_of,
     long long need = (n + wpb - 1) / wpb;
     int blocks = (int)std::min<long long>(need, (long long)ctx->num_cu * 16);
     if (blocks < 1) return MP_OK;
+    // Split mode: when the LDS slice leaves fewer than 4 waves per block (many samples per trajectory) and the
+    // scene is not tiny, the clearance profile is computed by clearance_kernel at full occupancy first.
+    if (c.model == MP_MODEL_BOX) {
+        const size_t pre_bytes = (size_t)n * (size_t)c.n_safe * (sizeof(T) + sizeof(int));
+        bool split = ctx->split_mode == 1 || (ctx->split_mode < 0 && wpb < 4 && c.n_safe > 64 && ctx->max_task_boxes >= 32);
+        if (split && pre_bytes <= ((size_t)16 << 30)) {
+            int rc = reserve(ctx, ctx->s_pre_d, (size_t)n * c.n_safe * sizeof(T));
+            if (rc) return rc;
+            if ((rc = reserve(ctx, ctx->s_pre_arg, (size_t)n * c.n_safe * sizeof(int)))) return rc;
+            a.pre_d = (T *)ctx->s_pre_d.p;
+            a.pre_arg = (int *)ctx->s_pre_arg.p;
+            const long long units = n * ((c.n_safe + 63) / 64);
+            const int cblocks = (int)std::min<long long>((units + 3) / 4, (long long)ctx->num_cu * 32);
+            const size_t clds = (size_t)4 * mp::clearance_lds_bytes_per_wave((int)sizeof(T));
+            if (ctx->has_rot)
+                hipLaunchKernelGGL((mp::clearance_kernel<T, true>), dim3(cblocks), dim3(256), clds, ctx->stream, a);
+            else
+                hipLaunchKernelGGL((mp::clearance_kernel<T, false>), dim3(cblocks), dim3(256), clds, ctx->stream, a);
+            HIP_TRY(ctx, hipGetLastError());
+        }
+    }
     const bool g = grad != nullptr;
     if (c.model == MP_MODEL_BOX)
         return g ? launch_eval_k<T, 1, true>(ctx, a, wpb, blocks, lds_bytes)
@@ -494,6 +537,7 @@ int mp_create(int device_id, int dtype, mp_ctx **out)
         return fail(nullptr, MP_E_ARG, "mp_create: device_id %d out of range (0..%d)", device_id, count - 1);
     mp_ctx *ctx = new mp_ctx();
     ctx->device = device_id;
+    if (const char *sm = std::getenv("MP_SPLIT_CLEARANCE")) ctx->split_mode = std::atoi(sm) != 0 ? 1 : 0;
     ctx->dtype = dtype;
     auto bail = [&](const char *what, hipError_t err) {
         fail(nullptr, MP_E_HIP, "mp_create: %s: %s", what, hipGetErrorString(err));
@@ -520,7 +564,7 @@ int mp_destroy(mp_ctx *ctx)
     hipStreamSynchronize(ctx->stream);
     DevBuf *bufs[] = {&ctx->boxes, &ctx->boxes32, &ctx->groups, &ctx->d_idx, &ctx->d_mask, &ctx->d_M, &ctx->d_My, &ctx->d_tsched, &ctx->d_tasks,
                       &ctx->s_X, &ctx->s_taskof, &ctx->s_cost, &ctx->s_terms, &ctx->s_grad, &ctx->s_minc,
-                      &ctx->s_flags, &ctx->s_dist, &ctx->s_aux0, &ctx->s_aux1, &ctx->c_X, &ctx->c_vals, &ctx->c_minc,
+                      &ctx->s_flags, &ctx->s_dist, &ctx->s_aux0, &ctx->s_aux1, &ctx->s_pre_d, &ctx->s_pre_arg, &ctx->c_X, &ctx->c_vals, &ctx->c_minc,
                       &ctx->c_flags, &ctx->c_mu, &ctx->c_sigma, &ctx->c_bestx, &ctx->c_bestval, &ctx->c_prev, &ctx->c_bminc,
                       &ctx->c_bflags, &ctx->c_done, &ctx->c_nit, &ctx->c_active, &ctx->c_task, &ctx->c_x0, &ctx->c_s0,
                       &ctx->c_noise};
@@ -651,6 +695,8 @@ int mp_set_problem(mp_ctx *ctx, const mp_config *cfg, int32_t n_tasks, const mp_
     ctx->have_problem = false;
     ctx->cfg = c;
     ctx->n_tasks = n_tasks;
+    ctx->max_task_boxes = 0;
+    for (int i = 0; i < n_tasks; ++i) ctx->max_task_boxes = std::max(ctx->max_task_boxes, (int)tasks[i].box_count);
     ctx->basis.assign((size_t)c.n_samples * c.n_ctrl, 0.0);
     if (c.basis) std::memcpy(ctx->basis.data(), c.basis, ctx->basis.size() * sizeof(double));
     else if ((rc = build_basis(c.n_ctrl, 3, c.n_samples, ctx->basis.data()))) return fail(ctx, rc, "basis construction failed");
@@ -875,3 +921,15 @@ int mp_cem_solve(mp_ctx *ctx, int64_t n_inst, const int32_t *task_of_inst, const
 }
 
 }  // extern "C"
+
+#ifdef MP_STATS
+// investigation build only (-DMP_STATS): read and reset the work counters of the clearance phase
+extern "C" int mp_debug_stats(unsigned long long *out8)
+{
+    if (hipDeviceSynchronize() != hipSuccess) return MP_E_HIP;
+    if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(mp::g_stats), 8 * sizeof(unsigned long long)) != hipSuccess) return MP_E_HIP;
+    unsigned long long z[8] = {0};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(mp::g_stats), z, sizeof(z)) != hipSuccess) return MP_E_HIP;
+    return MP_OK;
+}
+#endif

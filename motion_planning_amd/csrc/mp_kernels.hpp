@@ -13,6 +13,13 @@ namespace mp {
 #ifndef MP_MIN_WAVES
 #define MP_MIN_WAVES 3
 #endif
+#ifdef MP_STATS
+// investigation build only (tools/ build it into build_ab/): work counters of the clearance phase
+__device__ unsigned long long g_stats[8];
+#define MP_STAT_ADD(i, v) do { if (lane == 0) atomicAdd(&g_stats[i], (unsigned long long)(v)); } while (0)
+#else
+#define MP_STAT_ADD(i, v) do { } while (0)
+#endif
 constexpr int kMaxCtrl = 16;
 constexpr int kNTerms = 15;
 
@@ -22,7 +29,7 @@ template <typename T> struct DevTask {
     T normal[3];
     int has_normal, yaw_inc, box_begin, box_count;
     int sbox_begin;    // first record of this task's spatially sorted fp32 table (sboxes32)
-    int group_begin;   // first record of this task's group table
+    int group_begin;   // first group of this task in the group table (records 2*group_begin ...)
     int group_count;   // groups of kGroupSize consecutive sorted boxes (1 group: no group test)
     int pad;
 };
@@ -42,7 +49,8 @@ template <typename T> struct EvalArgs {
     const DevTask<T> *tasks;
     const BoxRec<T> *boxes;
     const BoxRec32 *boxes32;  // fp32 bound-pass table, sorted along a Morton curve per task; pad0 = original index
-    const BoxRec32 *groups;   // AABB of each group of consecutive sorted boxes; pad0/pad1 = first / count
+    const BoxRec32 *groups;   // per group of consecutive sorted boxes two records: [2g] AABB, pad0/pad1 = first / count;
+                              // [2g+1] centre of a representative box of the group
     float scene_radius;       // max |centre| + half extent over the scene (slack of the bound)
     const T *X;
     const int *task_of;
@@ -54,6 +62,9 @@ template <typename T> struct EvalArgs {
     long long n;
     T *cost, *terms, *grad, *minc, *dist;
     uint8_t *flags;
+    // split mode (large S): clearance_kernel fills these [n x Sp] tables, eval_kernel reads them
+    T *pre_d;      // clearance of every collision sample
+    int *pre_arg;  // its deciding box, relative to the task's range (-1: none)
 };
 
 // LDS slice of one wave (bytes).  Layout (S = samples, e = sizeof(T)):
@@ -67,8 +78,129 @@ __host__ __device__ inline int lds_bytes_per_wave(int S, int e)
     return (b + 15) & ~15;
 }
 
+// ---- culled clearance of one chunk of <= 64 collision samples (one per lane) against a task's boxes ----
+// P0/P1/P2/YW are indexed by sample (LOCAL: by the lane's slot 0..63); CC/SS/MINKEY/ARG point at the chunk's
+// first slot.  On return MINKEY[slot] holds the ordered key of the scene value, ARG[slot] the deciding box
+// (-1: none) and CC/SS the (cos, sin) of the sample's yaw.
+template <typename T, bool ROT, bool LOCAL>
+__device__ __forceinline__ void clearance_chunk(const EvalArgs<T> &a, const BoxRec<T> *boxes, const BoxRec32 *boxes32,
+                                                const BoxRec32 *groups, int ngroups, int lane, int k0, int Sp, const T *P0,
+                                                const T *P1, const T *P2, const T *YW, T *CC, T *SS,
+                                                unsigned long long *MINKEY, int *ARG, unsigned int *QUEUE)
+{
+    const float ax32 = (float)a.ax, ay32 = (float)a.ay, az32 = (float)a.az;
+    // this lane's own collision sample
+    const bool valid = k0 + lane < Sp;
+    float px32 = 0.f, py32 = 0.f, pz32 = 0.f, exs = 0.f, eys = 0.f, ezs = 0.f, slack = 0.f;
+    if (valid) {
+        const int s = LOCAL ? lane : a.idx_safe[k0 + lane];
+        T c, sn;
+        yaw_rot(YW[s], c, sn);
+        CC[lane] = c; SS[lane] = sn;
+        MINKEY[lane] = key_init<T>();
+        ARG[lane] = -1;
+        px32 = (float)P0[s]; py32 = (float)P1[s]; pz32 = (float)P2[s];
+        const float c32 = __builtin_fabsf((float)c), s32 = __builtin_fabsf((float)sn);
+        slack = 2e-6f * (__builtin_fabsf(px32) + __builtin_fabsf(py32) + __builtin_fabsf(pz32) +
+                         a.scene_radius + ax32 + ay32 + az32) + 1e-30f;
+        exs = __builtin_fmaf(s32, ay32, c32 * ax32) + slack;
+        eys = __builtin_fmaf(c32, ay32, s32 * ax32) + slack;
+        ezs = az32 + slack;
+    }
+    float U32 = __builtin_huge_valf();
+    int qhead = 0, qcount = 0;  // wave-uniform
+    MP_STAT_ADD(0, 1);
+    if (ngroups > 1) {
+        // Seed of the upper bound: the mover's centre lies in the mover and a box's centre in the box, so the scene
+        // value is at most the distance from this sample to the centre of any box.  One representative box per
+        // group (record 2g+1), coordinates inflated by the slack, keeps the first groups of the sweep from
+        // being evaluated against an infinite bound.
+        float ub = __builtin_huge_valf();
+        for (int g = 0; g < ngroups; ++g) {
+            const BoxRec32 rep = load_box32_uniform(groups, 2 * g + 1);
+            const float dx = __builtin_fabsf(px32 - rep.cx) + slack, dy = __builtin_fabsf(py32 - rep.cy) + slack,
+                        dz = __builtin_fabsf(pz32 - rep.cz) + slack;
+            ub = __builtin_fminf(ub, __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx)));
+        }
+        U32 = ub * (1.0f + 4e-6f);
+    }
+
+    // exact evaluation of up to 64 queued (sample, box) pairs, one per lane
+    auto drain = [&](int cnt) {
+        MP_STAT_ADD(3, cnt); MP_STAT_ADD(4, 1);
+        wave_lds_sync();
+        const bool act = lane < cnt;
+        unsigned long long key = ~0ull, oldk = 0ull;
+        int kk = 0, bb = 0;
+        if (act) {
+            const unsigned int e = QUEUE[(qhead + lane) & 127];
+            kk = (int)(e >> 24);
+            bb = (int)(e & 0xffffffu);
+            const int ss = LOCAL ? kk : a.idx_safe[k0 + kk];
+            const BoxRec<T> bx = boxes[bb];
+            T qx = P0[ss], qy = P1[ss], qc = CC[kk], qs = SS[kk], bcx = bx.cx, bcy = bx.cy;
+            if (ROT) {   // evaluate the pair in the box's own frame
+                to_box_frame(bx, qx, qy, qc, qs);
+                bcx = T(0); bcy = T(0);
+            }
+            Pose<T> ps;
+            pose_setup(ps, qx, qy, P2[ss], qc, qs, a.ax, a.ay);
+            key = pair_key(ps, a.ax, a.ay, a.az, bcx, bcy, bx.cz, bx.hx, bx.hy, bx.hz);
+            oldk = MINKEY[kk];
+        }
+        wave_lds_sync();
+        if (act) atomicMin(&MINKEY[kk], key);
+        wave_lds_sync();
+        bool win = false;
+        if (act) {
+            const unsigned long long newk = MINKEY[kk];
+            win = key == newk;
+            if (win && newk < oldk) ARG[kk] = 0x7fffffff;  // strictly better: restart the argmin
+        }
+        wave_lds_sync();
+        if (win) atomicMin(&ARG[kk], bb);  // ties: lowest box index, like a first-minimum scan
+        wave_lds_sync();
+        if (valid) U32 = (float)key_to_sep2<T>(MINKEY[lane]) * (1.0f + 4e-6f);
+    };
+
+    // Bound pass over the task's boxes in sorted order.  With several groups a whole group
+    // is skipped when no lane of the wave can be closer to its AABB than its current minimum.
+    for (int g = 0; g < ngroups; ++g) {
+        const BoxRec32 grp = load_box32_uniform(groups, 2 * g);
+        const int gfirst = __float_as_int(grp.pad0), gcnt = __float_as_int(grp.pad1);
+        if (ngroups > 1) {
+            const float lbg = aabb_lb2(px32, py32, pz32, exs, eys, ezs, grp);
+            if (!__builtin_amdgcn_ballot_w64(valid && (lbg <= U32))) continue;
+        }
+        MP_STAT_ADD(1, 1); MP_STAT_ADD(2, gcnt);
+        BoxRec32 nxt = load_box32_uniform(boxes32, gfirst);
+        for (int i = 0; i < gcnt; ++i) {
+            const BoxRec32 bx = nxt;
+            nxt = load_box32_uniform(boxes32, gfirst + (i + 1 < gcnt ? i + 1 : i));
+            const float lb2 = aabb_lb2(px32, py32, pz32, exs, eys, ezs, bx);
+            const bool need = valid && (lb2 <= U32);
+            const unsigned long long m = __builtin_amdgcn_ballot_w64(need);
+            if (m) {
+                if (need) {
+                    const int pos = __builtin_amdgcn_mbcnt_hi((unsigned int)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)m, 0u));
+                    QUEUE[(qhead + qcount + pos) & 127] = ((unsigned int)lane << 24) | (unsigned int)__float_as_int(bx.pad0);
+                }
+                qcount += __builtin_popcountll(m);
+                if (qcount >= 64) {
+                    drain(64);
+                    qhead = (qhead + 64) & 127;
+                    qcount -= 64;
+                }
+            }
+        }
+    }
+    if (qcount > 0) drain(qcount);
+    wave_lds_sync();
+}
+
 // ROT: the scene holds yaw-rotated static boxes (a separate instantiation keeps the axis-aligned code as it was)
-template <typename T, int MODEL, bool GRAD, bool ROT>
+// PRE: split mode, the clearance profile comes from clearance_kernel (box model only)
+template <typename T, int MODEL, bool GRAD, bool ROT, bool PRE>
 __global__ void __launch_bounds__(256, MP_MIN_WAVES) eval_kernel(const EvalArgs<T> a)
 {
     extern __shared__ __align__(16) unsigned char smem_raw[];
@@ -223,104 +355,28 @@ __global__ void __launch_bounds__(256, MP_MIN_WAVES) eval_kernel(const EvalArgs<
 
         // ---- clearance profile d_safe ----
         int Sp = a.Sp;
-        if (MODEL == 1) {
-            const BoxRec32 *boxes32 = a.boxes32 + __builtin_amdgcn_readfirstlane(tk.sbox_begin);
-            const BoxRec32 *groups = a.groups + __builtin_amdgcn_readfirstlane(tk.group_begin);
-            const int ngroups = __builtin_amdgcn_readfirstlane(tk.group_count);
-            const float ax32 = (float)a.ax, ay32 = (float)a.ay, az32 = (float)a.az;
-            for (int k0 = 0; k0 < Sp; k0 += 64) {
-                // this lane's own collision sample
-                const int k = k0 + lane;
-                const bool valid = k < Sp;
-                float px32 = 0.f, py32 = 0.f, pz32 = 0.f, exs = 0.f, eys = 0.f, ezs = 0.f;
-                if (valid) {
-                    const int s = a.idx_safe[k];
+        if (MODEL == 1 && PRE) {
+            // split mode: the clearance profile was computed by clearance_kernel (one wave per 64-sample chunk)
+            for (int k = lane; k < Sp; k += 64) {
+                const T d = a.pre_d[cand * a.Sp + k];
+                Dd[k] = d;
+                ARG[k] = a.pre_arg[cand * a.Sp + k];
+                if (GRAD) {
                     T c, sn;
-                    yaw_rot(YW[s], c, sn);
+                    yaw_rot(YW[a.idx_safe[k]], c, sn);
                     CC[k] = c; SS[k] = sn;
-                    MINKEY[k] = key_init<T>();
-                    ARG[k] = -1;
-                    px32 = (float)P0[s]; py32 = (float)P1[s]; pz32 = (float)P2[s];
-                    const float c32 = __builtin_fabsf((float)c), s32 = __builtin_fabsf((float)sn);
-                    const float slack = 2e-6f * (__builtin_fabsf(px32) + __builtin_fabsf(py32) + __builtin_fabsf(pz32) +
-                                                 a.scene_radius + ax32 + ay32 + az32) + 1e-30f;
-                    exs = __builtin_fmaf(s32, ay32, c32 * ax32) + slack;
-                    eys = __builtin_fmaf(c32, ay32, s32 * ax32) + slack;
-                    ezs = az32 + slack;
                 }
-                float U32 = __builtin_huge_valf();
-                int qhead = 0, qcount = 0;  // wave-uniform
-
-                // exact evaluation of up to 64 queued (sample, box) pairs, one per lane
-                auto drain = [&](int cnt) {
-                    wave_lds_sync();
-                    const bool act = lane < cnt;
-                    unsigned long long key = ~0ull, oldk = 0ull;
-                    int kk = 0, bb = 0;
-                    if (act) {
-                        const unsigned int e = QUEUE[(qhead + lane) & 127];
-                        kk = k0 + (int)(e >> 24);
-                        bb = (int)(e & 0xffffffu);
-                        const int ss = a.idx_safe[kk];
-                        const BoxRec<T> bx = boxes[bb];
-                        T qx = P0[ss], qy = P1[ss], qc = CC[kk], qs = SS[kk], bcx = bx.cx, bcy = bx.cy;
-                        if (ROT) {   // evaluate the pair in the box's own frame
-                            to_box_frame(bx, qx, qy, qc, qs);
-                            bcx = T(0); bcy = T(0);
-                        }
-                        Pose<T> ps;
-                        pose_setup(ps, qx, qy, P2[ss], qc, qs, a.ax, a.ay);
-                        key = pair_key(ps, a.ax, a.ay, a.az, bcx, bcy, bx.cz, bx.hx, bx.hy, bx.hz);
-                        oldk = MINKEY[kk];
-                    }
-                    wave_lds_sync();
-                    if (act) atomicMin(&MINKEY[kk], key);
-                    wave_lds_sync();
-                    bool win = false;
-                    if (act) {
-                        const unsigned long long newk = MINKEY[kk];
-                        win = key == newk;
-                        if (win && newk < oldk) ARG[kk] = 0x7fffffff;  // strictly better: restart the argmin
-                    }
-                    wave_lds_sync();
-                    if (win) atomicMin(&ARG[kk], bb);  // ties: lowest box index, like a first-minimum scan
-                    wave_lds_sync();
-                    if (valid) U32 = (float)key_to_sep2<T>(MINKEY[k]) * (1.0f + 4e-6f);
-                };
-
-                // Bound pass over the task's boxes in sorted order.  With several groups a whole group
-                // is skipped when no lane of the wave can be closer to its AABB than its current minimum.
-                for (int g = 0; g < ngroups; ++g) {
-                    const BoxRec32 grp = load_box32_uniform(groups, g);
-                    const int gfirst = __float_as_int(grp.pad0), gcnt = __float_as_int(grp.pad1);
-                    if (ngroups > 1) {
-                        const float lbg = aabb_lb2(px32, py32, pz32, exs, eys, ezs, grp);
-                        if (!__builtin_amdgcn_ballot_w64(valid && (lbg <= U32))) continue;
-                    }
-                    BoxRec32 nxt = load_box32_uniform(boxes32, gfirst);
-                    for (int i = 0; i < gcnt; ++i) {
-                        const BoxRec32 bx = nxt;
-                        nxt = load_box32_uniform(boxes32, gfirst + (i + 1 < gcnt ? i + 1 : i));
-                        const float lb2 = aabb_lb2(px32, py32, pz32, exs, eys, ezs, bx);
-                        const bool need = valid && (lb2 <= U32);
-                        const unsigned long long m = __builtin_amdgcn_ballot_w64(need);
-                        if (m) {
-                            if (need) {
-                                const int pos = __builtin_amdgcn_mbcnt_hi((unsigned int)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)m, 0u));
-                                QUEUE[(qhead + qcount + pos) & 127] = ((unsigned int)lane << 24) | (unsigned int)__float_as_int(bx.pad0);
-                            }
-                            qcount += __builtin_popcountll(m);
-                            if (qcount >= 64) {
-                                drain(64);
-                                qhead = (qhead + 64) & 127;
-                                qcount -= 64;
-                            }
-                        }
-                    }
-                }
-                if (qcount > 0) drain(qcount);
-                wave_lds_sync();
-                if (valid) {
+                if (a.dist) a.dist[cand * a.Sp + k] = d;
+            }
+        } else if (MODEL == 1) {
+            const BoxRec32 *boxes32 = a.boxes32 + __builtin_amdgcn_readfirstlane(tk.sbox_begin);
+            const BoxRec32 *groups = a.groups + 2 * __builtin_amdgcn_readfirstlane(tk.group_begin);
+            const int ngroups = __builtin_amdgcn_readfirstlane(tk.group_count);
+            for (int k0 = 0; k0 < Sp; k0 += 64) {
+                clearance_chunk<T, ROT, false>(a, boxes, boxes32, groups, ngroups, lane, k0, Sp, P0, P1, P2, YW, CC + k0, SS + k0,
+                                               MINKEY + k0, ARG + k0, QUEUE);
+                const int k = k0 + lane;
+                if (k < Sp) {
                     const T d = key_to_distance<T>(MINKEY[k]);
                     Dd[k] = d;
                     if (a.dist) a.dist[cand * a.Sp + k] = d;
@@ -606,6 +662,92 @@ __global__ void __launch_bounds__(256, MP_MIN_WAVES) eval_kernel(const EvalArgs<
             }
         }
         wave_lds_sync();  // the next candidate reuses the slice
+    }
+}
+
+// ---- split mode: the clearance profile on its own, one wave per (candidate, 64-sample chunk) --------------
+// With many samples per trajectory the LDS slice of eval_kernel leaves room for very few waves per CU, while
+// almost all of the work is the (sample x box) clearance phase.  This kernel needs ~5 KB of LDS per wave: it
+// recomputes the chunk's spline samples with the same fma chain (same bits) and writes d and the deciding box.
+__host__ __device__ inline int clearance_lds_bytes_per_wave(int e)
+{
+    return (64 + 6 * 64) * e + 8 * 64 + 4 * 64 + 4 * 128;   // W | P0 P1 P2 YW CC SS | MINKEY | ARG | QUEUE
+}
+
+template <typename T, bool ROT>
+__global__ void __launch_bounds__(256) clearance_kernel(const EvalArgs<T> a)
+{
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    const int lane = threadIdx.x & 63;
+    const int wib = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int wpb = (int)(blockDim.x >> 6);
+    const int C = a.C, Cy = a.Cy, nf = a.nf, ff = a.ff, nyf = a.nyf;
+    const int D = 3 * nf + nyf;
+    unsigned char *slice = smem_raw + (size_t)wib * clearance_lds_bytes_per_wave((int)sizeof(T));
+    T *W = reinterpret_cast<T *>(slice);
+    T *P0 = W + 64, *P1 = P0 + 64, *P2 = P1 + 64, *YW = P2 + 64, *CC = YW + 64, *SS = CC + 64;
+    unsigned long long *MINKEY = reinterpret_cast<unsigned long long *>(SS + 64);
+    int *ARG = reinterpret_cast<int *>(MINKEY + 64);
+    unsigned int *QUEUE = reinterpret_cast<unsigned int *>(ARG + 64);
+    const int chunks = (a.Sp + 63) >> 6;
+    const long long units = a.n * chunks;
+
+    for (long long u = (long long)blockIdx.x * wpb + wib; u < units; u += (long long)gridDim.x * wpb) {
+        const long long cand = u / chunks;
+        const int k0 = (int)(u - cand * chunks) << 6;
+        long long tl;
+        if (a.group_size > 0) {
+            const long long grp = cand / a.group_size;
+            if (a.group_done && a.group_done[grp]) continue;
+            tl = a.group_task ? (long long)a.group_task[grp] : 0;
+        } else {
+            tl = a.task_of ? (long long)a.task_of[cand] : (a.cpt > 0 ? cand / a.cpt : 0);
+        }
+        const int t = __builtin_amdgcn_readfirstlane((int)tl);
+        const DevTask<T> &tk = a.tasks[t];
+        const T *x = a.X + cand * D;
+        const BoxRec<T> *boxes = a.boxes + __builtin_amdgcn_readfirstlane(tk.box_begin);
+        const BoxRec32 *boxes32 = a.boxes32 + __builtin_amdgcn_readfirstlane(tk.sbox_begin);
+        const BoxRec32 *groups = a.groups + 2 * __builtin_amdgcn_readfirstlane(tk.group_begin);
+        const int ngroups = __builtin_amdgcn_readfirstlane(tk.group_count);
+        {   // waypoint table, as in eval_kernel
+            const int rows = C > Cy ? C : Cy;
+            for (int i = lane; i < rows * 4; i += 64) {
+                const int j = i >> 2, col = i & 3;
+                T v = T(0);
+                if (col < 3) {
+                    if (j < C) v = (j >= ff && j < ff + nf) ? x[3 * (j - ff) + col] : tk.ctrl[j][col];
+                } else if (j < Cy) {
+                    v = (j >= 1 && j <= nyf) ? x[3 * nf + (j - 1)] : tk.yaw_ctrl[j];
+                }
+                W[i] = v;
+            }
+        }
+        wave_lds_sync();
+        const int k = k0 + lane;
+        if (k < a.Sp) {   // this lane's sample, same fma chain as eval_kernel
+            const int s = a.idx_safe[k];
+            const T *m = a.M + (size_t)s * C;
+            T m0 = m[0];
+            T px = m0 * W[0], py = m0 * W[1], pz = m0 * W[2];
+            for (int j = 1; j < C; ++j) {
+                T mj = m[j];
+                px = mp_fma(mj, W[4 * j + 0], px);
+                py = mp_fma(mj, W[4 * j + 1], py);
+                pz = mp_fma(mj, W[4 * j + 2], pz);
+            }
+            const T *my = a.My + (size_t)s * Cy;
+            T yw = my[0] * W[3];
+            for (int j = 1; j < Cy; ++j) yw = mp_fma(my[j], W[4 * j + 3], yw);
+            P0[lane] = px; P1[lane] = py; P2[lane] = pz; YW[lane] = yw;
+        }
+        wave_lds_sync();
+        clearance_chunk<T, ROT, true>(a, boxes, boxes32, groups, ngroups, lane, k0, a.Sp, P0, P1, P2, YW, CC, SS, MINKEY, ARG, QUEUE);
+        if (k < a.Sp) {
+            a.pre_d[cand * a.Sp + k] = key_to_distance<T>(MINKEY[lane]);
+            a.pre_arg[cand * a.Sp + k] = ARG[lane];
+        }
+        wave_lds_sync();  // the next unit reuses the slice
     }
 }
 

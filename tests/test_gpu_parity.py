@@ -474,3 +474,39 @@ def test_tilted_static_box_is_refused(native):
     q = np.array([[0.0, 0.0, 0.5, 0.5]])
     assert ctx.lib.mp_set_scene(ctx._h, 1, p(one), p(one), p(one), p(one), p(one), p(one), p(q)) == abi.MP_E_ARG
     ctx.close()
+
+
+# ---- split mode: clearance profile by its own kernel (many samples per trajectory) ----------
+@pytest.mark.parametrize("force", ["1", "0", None])
+def test_split_clearance_mode_is_bit_identical(force, native, oracle_lib, monkeypatch):
+    """S=256 with 300 boxes selects the split automatically; forcing it on or off gives the same bits."""
+    from motion_planning_amd.synthetic import synthetic_candidates, synthetic_problem
+
+    if force is None:
+        monkeypatch.delenv("MP_SPLIT_CLEARANCE", raising=False)
+    else:
+        monkeypatch.setenv("MP_SPLIT_CLEARANCE", force)
+    prob = synthetic_problem(native.build_basis, 300, 256, seed=3, size_range=(0.05, 0.3))
+    X = synthetic_candidates(prob, 300, seed=4)
+    ref = oracle_lib.evaluate(prob, X)
+    for dt in (np.float64, np.float32):
+        ctx = native.Context(0, dt)
+        ctx.set_problem(prob)
+        Xd = X.astype(dt)
+        out = ctx.eval(Xd, want_grad=True, want_dist=True)
+        _compare(out, ref if dt is np.float64 else oracle_lib.evaluate(prob, Xd, dtype=dt), dt)
+        out2 = ctx.eval(Xd, want_grad=False, want_terms=False)
+        np.testing.assert_array_equal(out2["flags"], out["flags"])
+        np.testing.assert_array_equal(out2["min_clear"], out["min_clear"])
+        ctx.close()
+    # small S with the split forced on: several tasks, ragged chunk (S'=101 -> chunks of 64 + 37)
+    if force == "1":
+        names = ["base_step_01_first_on_ground", "base_step_04_between_two_blocks"]
+        probs = [H.problem_for_case(next(c for c in CASES if c["name"] == n)) for n in names]
+        rng = np.random.default_rng(5)
+        Xs = np.vstack([p.x0 + 0.5 * p.sigma0 * rng.normal(size=(33, p.dim)) for p in probs])
+        ctx = native.Context(0)
+        ctx.set_problem(probs)
+        ctx.set_cands_per_task(33)
+        _compare(ctx.eval(Xs, want_grad=True, want_dist=True), oracle_lib.evaluate(probs, Xs, cands_per_task=33), np.float64)
+        ctx.close()
