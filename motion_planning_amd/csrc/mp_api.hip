@@ -389,7 +389,7 @@ int launch_eval(mp_ctx *ctx, long long n, const void *X, const int32_t *task_of,
     a.nyf = c.n_yaw_free; a.Sp = c.n_safe; a.last_cond = c.last_if_not_close; a.keep_n = c.keep_n;
     a.use_pref = c.use_pref; a.tail_start = c.tail_start; a.use_goal_target = c.use_goal_target;
     a.goal_tail_n = c.goal_tail_n; a.mask = c.term_mask;
-    a.lds_per_wave = mp::lds_bytes_per_wave(c.n_samples, (int)sizeof(T));
+    a.lds_per_wave = mp::lds_bytes_per_wave(c.n_samples, (int)sizeof(T), grad != nullptr);
     a.n_tasks = ctx->n_tasks;
     for (int i = 0; i < MP_NTERMS; ++i) a.w[i] = (T)c.weights[i];
     a.req = (T)c.required_clearance; a.pref = (T)c.preferred_clearance; a.appr_tgt = (T)c.approach_target;
@@ -406,11 +406,20 @@ int launch_eval(mp_ctx *ctx, long long n, const void *X, const int32_t *task_of,
     a.flags = flags;
 
     const size_t per_wave = (size_t)a.lds_per_wave;
-    int wpb = (int)std::min<size_t>(4, std::max<size_t>(1, 65536 / per_wave));
-    const size_t lds_bytes = per_wave * wpb;
-    if (lds_bytes > ctx->max_lds)
+    if (per_wave > ctx->max_lds)
         return fail(ctx, MP_E_UNSUPPORTED, "n_samples_curve=%d needs %zu B of LDS per wave (limit %zu)", c.n_samples,
                     per_wave, ctx->max_lds);
+    // waves per block: whatever puts the most waves on a CU (blocks share its LDS), larger blocks on ties
+    int wpb = 1;
+    {
+        size_t best = 0;
+        for (int w = 1; w <= 4; ++w) {
+            if (per_wave * w > ctx->max_lds || (w > 1 && per_wave * w > 65536)) break;
+            const size_t waves = std::min<size_t>(ctx->max_lds / (per_wave * w), 16) * w;
+            if (waves >= best) { best = waves; wpb = w; }
+        }
+    }
+    const size_t lds_bytes = per_wave * wpb;
     long long need = (n + wpb - 1) / wpb;
     int blocks = (int)std::min<long long>(need, (long long)ctx->num_cu * 16);
     if (blocks < 1) return MP_OK;

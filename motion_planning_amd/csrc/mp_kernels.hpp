@@ -68,11 +68,14 @@ template <typename T> struct EvalArgs {
 };
 
 // LDS slice of one wave (bytes).  Layout (S = samples, e = sizeof(T)):
-//   W[64] | P[3][S] YAW[S] | GP[3][S] GY[S] | D[S] GD[S] | CC[S] SS[S] | D1[3][S] A1[3][S] A2[3][S] SEGW[S]   (T)
+//   W[64] | P[3][S] YAW[S] | D[S] | CC[S] SS[S] | D1[3][S]                        (T; every launch: 10 arrays)
+//   | GP[3][S] GY[S] | GD[S] | A1[3][S] A2[3][S] | SEGW[S]                         (T; gradient launches: 12 more)
 //   | MINKEY[S] (u64) | ARG[S] (int) | QUEUE[128] (u32)
-__host__ __device__ inline int lds_bytes_per_wave(int S, int e)
+// A cost-only launch (the CEM populations) needs less than half of a gradient launch's slice.
+__host__ __device__ inline int lds_arrays(bool grad) { return grad ? 22 : 10; }
+__host__ __device__ inline int lds_bytes_per_wave(int S, int e, bool grad)
 {
-    int b = (64 + 22 * S) * e;
+    int b = (64 + lds_arrays(grad) * S) * e;
     b = (b + 7) & ~7;
     b += 8 * S + 4 * S + 4 * 128;
     return (b + 15) & ~15;
@@ -212,15 +215,17 @@ __global__ void __launch_bounds__(256, MP_MIN_WAVES) eval_kernel(const EvalArgs<
     T *base = reinterpret_cast<T *>(smem_raw + (size_t)wib * a.lds_per_wave);
     T *W = base;
     T *P0 = W + 64, *P1 = P0 + S, *P2 = P1 + S, *YW = P2 + S;
-    T *G0 = YW + S, *G1 = G0 + S, *G2 = G1 + S, *GY = G2 + S;
-    T *Dd = GY + S, *GD = Dd + S;
-    T *CC = GD + S, *SS = CC + S;
+    T *Dd = YW + S;
+    T *CC = Dd + S, *SS = CC + S;
     T *D1x = SS + S, *D1y = D1x + S, *D1z = D1y + S;
-    T *A1x = D1z + S, *A1y = A1x + S, *A1z = A1y + S;
+    // gradient launches only (the slice of a cost-only launch ends here)
+    T *G0 = D1z + S, *G1 = G0 + S, *G2 = G1 + S, *GY = G2 + S;
+    T *GD = GY + S;
+    T *A1x = GD + S, *A1y = A1x + S, *A1z = A1y + S;
     T *A2x = A1z + S, *A2y = A2x + S, *A2z = A2y + S;
     T *SEGW = A2z + S;
-    unsigned long long *MINKEY =
-        reinterpret_cast<unsigned long long *>(smem_raw + (size_t)wib * a.lds_per_wave + (((64 + 22 * S) * sizeof(T) + 7) & ~(size_t)7));
+    unsigned long long *MINKEY = reinterpret_cast<unsigned long long *>(
+        smem_raw + (size_t)wib * a.lds_per_wave + (((64 + lds_arrays(GRAD) * S) * sizeof(T) + 7) & ~(size_t)7));
     int *ARG = reinterpret_cast<int *>(MINKEY + S);
     unsigned int *QUEUE = reinterpret_cast<unsigned int *>(ARG + S);
     const unsigned mask = a.mask;
