@@ -423,11 +423,14 @@ int launch_eval(mp_ctx *ctx, long long n, const void *X, const int32_t *task_of,
     long long need = (n + wpb - 1) / wpb;
     int blocks = (int)std::min<long long>(need, (long long)ctx->num_cu * 16);
     if (blocks < 1) return MP_OK;
-    // Split mode: when the LDS slice leaves fewer than 4 waves per block (many samples per trajectory) and the
-    // scene is not tiny, the clearance profile is computed by clearance_kernel at full occupancy first.
+    // Split mode: the clearance profile is computed by clearance_kernel first (full occupancy whatever S is, bound
+    // seeded from group representatives) when the scene is large enough to have box groups (>= 128 boxes in a
+    // task), or when a trajectory has more than one 64-sample chunk and the scene is not tiny.  Measured on
+    // MI355X (tools/shape_bench.py): B=200 S=64 -9 %, B=2000 S=64 -13 %, B=50 S=256 -32 %, B=2000 S=256 -75 %;
+    // B=13 S=101 and B=50 S=64 are faster fused.
     if (c.model == MP_MODEL_BOX) {
         const size_t pre_bytes = (size_t)n * (size_t)c.n_safe * (sizeof(T) + sizeof(int));
-        bool split = ctx->split_mode == 1 || (ctx->split_mode < 0 && wpb < 4 && c.n_safe > 64 && ctx->max_task_boxes >= 32);
+        bool split = ctx->split_mode == 1 || (ctx->split_mode < 0 && (ctx->max_task_boxes >= 128 || (c.n_safe > 64 && ctx->max_task_boxes >= 32)));
         if (split && pre_bytes <= ((size_t)16 << 30)) {
             int rc = reserve(ctx, ctx->s_pre_d, (size_t)n * c.n_safe * sizeof(T));
             if (rc) return rc;

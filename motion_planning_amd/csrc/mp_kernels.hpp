@@ -83,9 +83,10 @@ __host__ __device__ inline int lds_bytes_per_wave(int S, int e, bool grad)
 
 // ---- culled clearance of one chunk of <= 64 collision samples (one per lane) against a task's boxes ----
 // P0/P1/P2/YW are indexed by sample (LOCAL: by the lane's slot 0..63); CC/SS/MINKEY/ARG point at the chunk's
-// first slot.  On return MINKEY[slot] holds the ordered key of the scene value, ARG[slot] the deciding box
+// first slot.  SEED: start from an upper bound taken from one representative box per group (used by the split
+// kernel, which serves every scene large enough to have groups).  On return MINKEY[slot] holds the ordered key of the scene value, ARG[slot] the deciding box
 // (-1: none) and CC/SS the (cos, sin) of the sample's yaw.
-template <typename T, bool ROT, bool LOCAL>
+template <typename T, bool ROT, bool LOCAL, bool SEED>
 __device__ __forceinline__ void clearance_chunk(const EvalArgs<T> &a, const BoxRec<T> *boxes, const BoxRec32 *boxes32,
                                                 const BoxRec32 *groups, int ngroups, int lane, int k0, int Sp, const T *P0,
                                                 const T *P1, const T *P2, const T *YW, T *CC, T *SS,
@@ -113,7 +114,7 @@ __device__ __forceinline__ void clearance_chunk(const EvalArgs<T> &a, const BoxR
     float U32 = __builtin_huge_valf();
     int qhead = 0, qcount = 0;  // wave-uniform
     MP_STAT_ADD(0, 1);
-    if (ngroups > 1) {
+    if (SEED && ngroups > 1) {
         // Seed of the upper bound: the mover's centre lies in the mover and a box's centre in the box, so the scene
         // value is at most the distance from this sample to the centre of any box.  One representative box per
         // group (record 2g+1), coordinates inflated by the slack, keeps the first groups of the sweep from
@@ -378,7 +379,7 @@ __global__ void __launch_bounds__(256, MP_MIN_WAVES) eval_kernel(const EvalArgs<
             const BoxRec32 *groups = a.groups + 2 * __builtin_amdgcn_readfirstlane(tk.group_begin);
             const int ngroups = __builtin_amdgcn_readfirstlane(tk.group_count);
             for (int k0 = 0; k0 < Sp; k0 += 64) {
-                clearance_chunk<T, ROT, false>(a, boxes, boxes32, groups, ngroups, lane, k0, Sp, P0, P1, P2, YW, CC + k0, SS + k0,
+                clearance_chunk<T, ROT, false, false>(a, boxes, boxes32, groups, ngroups, lane, k0, Sp, P0, P1, P2, YW, CC + k0, SS + k0,
                                                MINKEY + k0, ARG + k0, QUEUE);
                 const int k = k0 + lane;
                 if (k < Sp) {
@@ -747,7 +748,7 @@ __global__ void __launch_bounds__(256) clearance_kernel(const EvalArgs<T> a)
             P0[lane] = px; P1[lane] = py; P2[lane] = pz; YW[lane] = yw;
         }
         wave_lds_sync();
-        clearance_chunk<T, ROT, true>(a, boxes, boxes32, groups, ngroups, lane, k0, a.Sp, P0, P1, P2, YW, CC, SS, MINKEY, ARG, QUEUE);
+        clearance_chunk<T, ROT, true, true>(a, boxes, boxes32, groups, ngroups, lane, k0, a.Sp, P0, P1, P2, YW, CC, SS, MINKEY, ARG, QUEUE);
         if (k < a.Sp) {
             a.pre_d[cand * a.Sp + k] = key_to_distance<T>(MINKEY[lane]);
             a.pre_arg[cand * a.Sp + k] = ARG[lane];

@@ -1,0 +1,27 @@
+#!/usr/bin/env python3
+"""Kernel time of one mp_eval launch for a list of (boxes, samples, candidates) shapes (fp64, cost+grad)."""
+import sys
+from pathlib import Path
+
+import numpy as np
+import torch
+
+sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
+from motion_planning_amd import _native  # noqa: E402
+from motion_planning_amd.batch import DeviceBatch  # noqa: E402
+from motion_planning_amd.synthetic import synthetic_candidates, synthetic_problem  # noqa: E402
+
+shapes = [(50, 64, 65536), (50, 101, 32768), (13, 101, 65536), (200, 64, 32768), (2000, 64, 16384), (50, 256, 16384), (2000, 256, 16384)]
+for B, S, N in shapes:
+    prob = synthetic_problem(_native.build_basis, B, S, seed=1 if B >= 1000 else 0, size_range=(0.05, 0.3) if B >= 1000 else (0.1, 0.6))
+    X = torch.from_numpy(synthetic_candidates(prob, N, seed=5)).cuda()
+    for grad in (True, False):
+        db = DeviceBatch(prob, N, want_grad=grad)
+        db.evaluate(X)
+        db.ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+        db.ctx.timer_start()
+        for _ in range(5):
+            db.evaluate(X)
+        ms = db.ctx.timer_stop() / 5
+        print(f"B={B:5d} S={S:4d} N={N:6d} grad={grad!s:5}: {ms:8.3f} ms  {N / ms * 1e3:.3e} evals/s", flush=True)
+        db.close()
