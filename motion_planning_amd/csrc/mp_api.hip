@@ -415,7 +415,8 @@ int launch_eval(mp_ctx *ctx, long long n, const void *X, const int32_t *task_of,
         size_t best = 0;
         for (int w = 1; w <= 4; ++w) {
             if (per_wave * w > ctx->max_lds || (w > 1 && per_wave * w > 65536)) break;
-            const size_t waves = std::min<size_t>(ctx->max_lds / (per_wave * w), 16) * w;
+            // 12 = the 3 waves per SIMD the kernels' VGPR budget (__launch_bounds__(256, MP_MIN_WAVES)) allows on a CU
+            const size_t waves = std::min<size_t>(std::min<size_t>(ctx->max_lds / (per_wave * w), 16) * w, 12);
             if (waves >= best) { best = waves; wpb = w; }
         }
     }
