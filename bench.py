@@ -40,23 +40,38 @@ def algorithmic_flops(S, Sp, B, C):
     return Sp * B * 200 + S * 160 + 16 * S * C
 
 
-def cpu_baseline(problem, X, budget_s=10.0):
-    """The C oracle ("port") on ONE host core over a bounded sample of the same workload."""
+def cpu_baseline(problem, X, budget_s=8.0):
+    """The C oracle ("port") on the box's host cores over a bounded sample of the same workload: first on ONE
+    core (the reference itself is single-threaded Python), then on `cores` threads (ctypes releases the GIL, every
+    call owns its workspace) — the second figure is the reported value, the honest best-CPU number."""
+    from concurrent.futures import ThreadPoolExecutor
+
     from oracle import oracle as orc
 
     orc.build()
     orc.evaluate(problem, X[:64])
-    done, t0, chunk = 0, time.perf_counter(), 4096
-    while True:
-        lo = done % X.shape[0]
+    chunk = 2048
+
+    def run(lo):
         orc.evaluate(problem, X[lo:lo + chunk], want_grad=True, want_dist=False)
-        done += min(chunk, X.shape[0] - lo)
-        el = time.perf_counter() - t0
-        if el >= budget_s:
-            break
-    return {"value": done / el, "unit": "evals/s", "cores": 1, "kind": "port",
-            "sample": f"{done} candidates of the same batch (64 samples x 50 boxes, fp64, cost+grad), "
-                      f"{el:.1f} s of oracle/mp_oracle.c on one core of {os.cpu_count()} visible"}
+        return min(chunk, X.shape[0] - lo)
+
+    done, t0 = 0, time.perf_counter()
+    while time.perf_counter() - t0 < budget_s:
+        done += run(done % X.shape[0])
+    one = done / (time.perf_counter() - t0)
+    # the GPU box shows the whole machine's CPUs; a one-GPU job's share is 16
+    cores = max(1, min(16, int(os.environ.get("OMP_NUM_THREADS", "16")), os.cpu_count() or 1))
+    starts = list(range(0, X.shape[0] - chunk + 1, chunk))
+    total, t0 = 0, time.perf_counter()
+    with ThreadPoolExecutor(max_workers=cores) as pool:
+        while time.perf_counter() - t0 < budget_s:
+            total += sum(pool.map(run, starts[:4 * cores]))
+    el = time.perf_counter() - t0
+    return {"value": total / el, "unit": "evals/s", "cores": cores, "kind": "port", "value_one_core": one,
+            "sample": f"{total} candidates of the same batch (64 samples x 50 boxes, fp64, cost+grad) in {el:.1f} s of "
+                      f"oracle/mp_oracle.c on {cores} threads; {done} candidates in {budget_s:.0f} s on one core "
+                      f"({os.cpu_count()} CPUs visible)"}
 
 
 def main():
