@@ -247,6 +247,7 @@ def main():
         print(json.dumps(line))
     db.close()
     if world > 1:
+        dist.barrier()   # rank 0 prints and times the CPU baseline last; nobody tears the group down early
         dist.destroy_process_group()
 
 

@@ -54,6 +54,8 @@ struct mp_ctx {
 
     // staging for MP_MEM_HOST calls
     DevBuf s_X, s_taskof, s_cost, s_terms, s_grad, s_minc, s_flags, s_dist, s_aux0, s_aux1;
+    void *h_pin = nullptr;        // pinned, device-visible host staging for small host-buffer calls (zero copy)
+    size_t h_pin_cap = 0;
     DevBuf s_pre_d, s_pre_arg;    // split mode: clearance profile + deciding box of every (candidate, sample)
     int max_task_boxes = 0;
     int split_mode = -1;          // -1 automatic, 0 never, 1 always (MP_SPLIT_CLEARANCE, tuning aid)
@@ -102,6 +104,8 @@ int upload(mp_ctx *ctx, DevBuf &b, const void *src, size_t bytes)
 }
 
 size_t esize(const mp_ctx *ctx) { return ctx->dtype == MP_F64 ? 8 : 4; }
+
+constexpr size_t kPinnedCallBytes = (size_t)256 << 10;  // host-buffer calls up to this size go through pinned memory
 
 // ---- interpolating B-spline sampling matrix (host, once per problem) --------------------
 // Restates what scipy.interpolate.make_interp_spline(u, y, k) with bc_type=None does for
@@ -583,6 +587,7 @@ int mp_destroy(mp_ctx *ctx)
                       &ctx->c_noise};
     for (DevBuf *b : bufs)
         if (b->p) hipFree(b->p);
+    if (ctx->h_pin) hipHostFree(ctx->h_pin);
     if (ctx->ev0) hipEventDestroy(ctx->ev0);
     if (ctx->ev1) hipEventDestroy(ctx->ev1);
     if (ctx->own_stream) hipStreamDestroy(ctx->own_stream);
@@ -774,6 +779,51 @@ int mp_eval(mp_ctx *ctx, int64_t n, const void *X, const int32_t *task_of, void 
     if (task_of)
         for (int64_t i = 0; i < n; ++i)
             if (task_of[i] < 0 || task_of[i] >= ctx->n_tasks) return fail(ctx, MP_E_ARG, "mp_eval: task_of[%lld] out of range", (long long)i);
+    {
+        // Small calls (one x from SciPy's Powell, one CEM population): the kernel reads X from and writes its results
+        // to pinned host memory directly, so the call is one launch and one stream synchronisation instead of up to
+        // eight copy commands (measured: 66-100 us -> see DESIGN.md 7).
+        auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
+        const size_t bX = up((size_t)n * D * es), bT = task_of ? up((size_t)n * 4) : 0, bC = up((size_t)n * es);
+        const size_t bTerms = terms ? up((size_t)n * MP_NTERMS * es) : 0, bG = grad ? up((size_t)n * D * es) : 0;
+        const size_t bM = min_clear ? up((size_t)n * es) : 0, bF = flags ? up((size_t)n) : 0;
+        const size_t bD = dist ? up((size_t)n * c.n_safe * es) : 0;
+        const size_t total = bX + bT + bC + bTerms + bG + bM + bF + bD;
+        if (total <= kPinnedCallBytes) {
+            if (total > ctx->h_pin_cap) {
+                if (ctx->h_pin) HIP_TRY(ctx, hipHostFree(ctx->h_pin));
+                ctx->h_pin = nullptr; ctx->h_pin_cap = 0;
+                HIP_TRY(ctx, hipHostMalloc(&ctx->h_pin, kPinnedCallBytes, hipHostMallocDefault));
+                ctx->h_pin_cap = kPinnedCallBytes;
+            }
+            unsigned char *q = (unsigned char *)ctx->h_pin;
+            unsigned char *pX = q; q += bX;
+            unsigned char *pT = q; q += bT;
+            unsigned char *pC = q; q += bC;
+            unsigned char *pTerms = q; q += bTerms;
+            unsigned char *pG = q; q += bG;
+            unsigned char *pM = q; q += bM;
+            unsigned char *pF = q; q += bF;
+            unsigned char *pD = q;
+            std::memcpy(pX, X, (size_t)n * D * es);
+            if (task_of) std::memcpy(pT, task_of, (size_t)n * 4);
+            const int32_t *zt = task_of ? (const int32_t *)pT : nullptr;
+            void *zterms = terms ? pTerms : nullptr, *zg = grad ? pG : nullptr, *zm = min_clear ? pM : nullptr;
+            void *zd = dist ? pD : nullptr;
+            uint8_t *zf = flags ? pF : nullptr;
+            rc = ctx->dtype == MP_F64 ? launch_eval<double>(ctx, n, pX, zt, pC, zterms, zg, zm, zf, zd)
+                                      : launch_eval<float>(ctx, n, pX, zt, pC, zterms, zg, zm, zf, zd);
+            if (rc) return rc;
+            HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+            std::memcpy(cost, pC, (size_t)n * es);
+            if (terms) std::memcpy(terms, pTerms, (size_t)n * MP_NTERMS * es);
+            if (grad) std::memcpy(grad, pG, (size_t)n * D * es);
+            if (min_clear) std::memcpy(min_clear, pM, (size_t)n * es);
+            if (flags) std::memcpy(flags, pF, (size_t)n);
+            if (dist) std::memcpy(dist, pD, (size_t)n * c.n_safe * es);
+            return MP_OK;
+        }
+    }
     if ((rc = upload(ctx, ctx->s_X, X, (size_t)n * D * es))) return rc;
     if (task_of && (rc = upload(ctx, ctx->s_taskof, task_of, (size_t)n * sizeof(int32_t)))) return rc;
     if ((rc = reserve(ctx, ctx->s_cost, (size_t)n * es))) return rc;
