@@ -169,7 +169,8 @@ int mp_timer_stop(mp_ctx *ctx, float *elapsed_ms); /* synchronises on the stop e
  * evaluated in the box's own frame.  A box tilted about x or y returns
  * MP_E_UNSUPPORTED (no shipped scenario has one); a quaternion
  * that is not of unit length returns MP_E_ARG.
- * n_boxes == 0 is legal: distances are +inf (scene.py:112-113). */
+ * n_boxes == 0 is legal: distances are +inf (scene.py:112-113).  Replacing the scene
+ * invalidates the current problem: call mp_set_problem again before mp_eval. */
 int mp_set_scene(mp_ctx *ctx, int32_t n_boxes, const double *cx, const double *cy,
                  const double *cz, const double *hx, const double *hy, const double *hz,
                  const double *quat_xyzw /* [n_boxes x 4] or NULL */);

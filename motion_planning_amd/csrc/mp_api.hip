@@ -673,6 +673,7 @@ int mp_set_scene(mp_ctx *ctx, int32_t n_boxes, const double *cx, const double *c
     if (rc) return rc;
     ctx->n_boxes = n_boxes;
     ctx->have_scene = true;
+    ctx->have_problem = false;  // a problem's box ranges and bound tables belong to the scene it was set on
     return MP_OK;
 }
 

@@ -510,3 +510,45 @@ def test_split_clearance_mode_is_bit_identical(force, native, oracle_lib, monkey
         ctx.set_cands_per_task(33)
         _compare(ctx.eval(Xs, want_grad=True, want_dist=True), oracle_lib.evaluate(probs, Xs, cands_per_task=33), np.float64)
         ctx.close()
+
+
+def test_planner_surface_with_a_rotated_static_block(oracle_lib):
+    """Scene with a block turned 30 deg about z through the drop-in surface: queries match the oracle exactly and a
+    seeded CEM solve on the GPU equals the same host logic driven by the oracle."""
+    from motion_planning_amd import spline_opt as so
+    from motion_planning_amd.problem import scene_to_boxes
+    from motion_planning_amd.scene import Scene
+    from motion_planning_amd.spline_opt import yaw_deg_to_quat
+    from oracle.oracle import OracleEvaluator
+
+    s = Scene()
+    s.add_block((2.0, 2.0, 0.1), (0.0, 0.0, 0.05), object_id="table")
+    s.add_block((0.9, 0.3, 0.8), (0.1, 0.0, 0.5), quat=yaw_deg_to_quat(30.0), object_id="slab")
+    rows = scene_to_boxes(s)
+    assert rows.shape == (2, 8)
+    pos = np.array([[0.0, 0.45, 0.6], [0.6, -0.1, 0.5], [0.1, 0.0, 0.5]])
+    for p, yaw in zip(pos, (0.0, 75.0, -20.0)):
+        got = s.signed_distance_block((0.6, 0.4, 0.3), tuple(p), yaw_deg_to_quat(yaw))
+        assert got == oracle_lib.box_sdf(rows, (0.6, 0.4, 0.3), p[None, :], np.array([yaw]))[0]
+        assert s.signed_distance(tuple(p)) == oracle_lib.point_sdf(rows, p[None, :])[0]
+    kw = dict(n_vias=2, n_samples_curve=64, moving_block_size=(0.4, 0.3, 0.2), start_yaw_deg=0.0, goal_yaw_deg=60.0,
+              safety_margin=0.02, preferred_safety_margin=0.08, w_safe_preferred=5.0, w_yaw_monotonic=1.0, method="CEM",
+              options={"population_size": 32, "max_iter": 12, "seed": 5})
+    start, goal = (-0.8, -0.6, 0.9), (0.8, 0.6, 0.4)
+    _, vias_g, info_g = so.optimize_bspline_path(s, start, goal, **kw)
+    _, vias_o, info_o = so.optimize_bspline_path(s, start, goal, evaluator_factory=OracleEvaluator, **kw)
+    assert info_g["nit"] == info_o["nit"]
+    assert info_g["fun"] == pytest.approx(info_o["fun"], rel=1e-9)
+    np.testing.assert_allclose(vias_g, vias_o, rtol=1e-9, atol=1e-12)
+    assert info_g["min_clearance"] == info_o["min_clearance"]
+
+
+def test_new_scene_invalidates_the_problem(native):
+    prob = H.problem_for_case(CASES[0])
+    ctx = native.Context(0)
+    ctx.set_problem(prob)
+    ctx.eval(prob.x0[None, :])
+    ctx.set_scene(prob.boxes[:1])
+    with pytest.raises(native.NativeError, match="mp_set_problem first"):
+        ctx.eval(prob.x0[None, :])
+    ctx.close()
