@@ -58,6 +58,7 @@ struct mp_ctx {
     size_t h_pin_cap = 0;
     DevBuf s_pre_d, s_pre_arg;    // split mode: clearance profile + deciding box of every (candidate, sample)
     int max_task_boxes = 0;
+    int idx_identity = 0;         // idx_safe is 0, 1, 2, ...
     int split_mode = -1;          // -1 automatic, 0 never, 1 always (MP_SPLIT_CLEARANCE, tuning aid)
 
     // device-resident CEM
@@ -399,7 +400,7 @@ int launch_eval(mp_ctx *ctx, long long n, const void *X, const int32_t *task_of,
     a.req = (T)c.required_clearance; a.pref = (T)c.preferred_clearance; a.appr_tgt = (T)c.approach_target;
     a.goal_tgt = (T)c.goal_clearance_target; a.radius = (T)c.point_radius;
     a.ax = (T)c.half_extents[0]; a.ay = (T)c.half_extents[1]; a.az = (T)c.half_extents[2];
-    a.idx_safe = (const int *)ctx->d_idx.p; a.amask = (const uint8_t *)ctx->d_mask.p;
+    a.idx_safe = (const int *)ctx->d_idx.p; a.idx_identity = ctx->idx_identity; a.amask = (const uint8_t *)ctx->d_mask.p;
     a.M = (const T *)ctx->d_M.p; a.My = (const T *)ctx->d_My.p; a.tsched = (const T *)ctx->d_tsched.p;
     a.tasks = (const mp::DevTask<T> *)ctx->d_tasks.p; a.boxes = (const mp::BoxRec<T> *)ctx->boxes.p;
     a.boxes32 = (const mp::BoxRec32 *)ctx->boxes32.p; a.groups = (const mp::BoxRec32 *)ctx->groups.p;
@@ -724,6 +725,9 @@ int mp_set_problem(mp_ctx *ctx, const mp_config *cfg, int32_t n_tasks, const mp_
     else if ((rc = build_basis(c.n_yaw_ctrl, std::min(3, c.n_yaw_ctrl - 1), c.n_samples, ctx->basis_yaw.data())))
         return fail(ctx, rc, "yaw basis construction failed");
     if ((rc = upload(ctx, ctx->d_idx, c.idx_safe, (size_t)c.n_safe * sizeof(int32_t)))) return rc;
+    ctx->idx_identity = 1;
+    for (int k = 0; k < c.n_safe; ++k)
+        if (c.idx_safe[k] != k) { ctx->idx_identity = 0; break; }
     if ((rc = upload(ctx, ctx->d_mask, c.approach_mask, (size_t)c.n_safe))) return rc;
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     rc = ctx->dtype == MP_F64 ? upload_problem<double>(ctx, tasks) : upload_problem<float>(ctx, tasks);
@@ -994,6 +998,15 @@ extern "C" int mp_debug_stats(unsigned long long *out8)
     if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(mp::g_stats), 8 * sizeof(unsigned long long)) != hipSuccess) return MP_E_HIP;
     unsigned long long z[8] = {0};
     if (hipMemcpyToSymbol(HIP_SYMBOL(mp::g_stats), z, sizeof(z)) != hipSuccess) return MP_E_HIP;
+    return MP_OK;
+}
+
+extern "C" int mp_debug_phases(unsigned long long *out16)
+{
+    if (hipDeviceSynchronize() != hipSuccess) return MP_E_HIP;
+    if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(mp::g_phase), 16 * sizeof(unsigned long long)) != hipSuccess) return MP_E_HIP;
+    unsigned long long z[16] = {0};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(mp::g_phase), z, sizeof(z)) != hipSuccess) return MP_E_HIP;
     return MP_OK;
 }
 #endif

@@ -17,8 +17,15 @@ namespace mp {
 // investigation build only (tools/ build it into build_ab/): work counters of the clearance phase
 __device__ unsigned long long g_stats[8];
 #define MP_STAT_ADD(i, v) do { if (lane == 0) atomicAdd(&g_stats[i], (unsigned long long)(v)); } while (0)
+// phase clock of eval_kernel: cycles since the previous mark are added to g_phase[i]
+__device__ unsigned long long g_phase[16];
+#define MP_PHASE_INIT unsigned long long mp_t_prev = __builtin_readcyclecounter()
+#define MP_PHASE(i) do { unsigned long long mp_t_now = __builtin_readcyclecounter(); \
+        if (lane == 0) atomicAdd(&g_phase[i], mp_t_now - mp_t_prev); mp_t_prev = mp_t_now; } while (0)
 #else
 #define MP_STAT_ADD(i, v) do { } while (0)
+#define MP_PHASE_INIT do { } while (0)
+#define MP_PHASE(i) do { } while (0)
 #endif
 constexpr int kMaxCtrl = 16;
 constexpr int kNTerms = 15;
@@ -42,6 +49,7 @@ template <typename T> struct EvalArgs {
     T w[kNTerms];
     T req, pref, appr_tgt, goal_tgt, radius, ax, ay, az;
     const int *idx_safe;
+    int idx_identity;   // idx_safe[k] == k for every k (collision_check_subsample == 1): the table is not read
     const uint8_t *amask;
     const T *M;
     const T *My;
@@ -66,6 +74,12 @@ template <typename T> struct EvalArgs {
     T *pre_d;      // clearance of every collision sample
     int *pre_arg;  // its deciding box, relative to the task's range (-1: none)
 };
+
+// collision sample k -> spline sample (identity unless the path is subsampled for collision checks)
+template <typename T> __device__ __forceinline__ int sample_of(const EvalArgs<T> &a, int k)
+{
+    return a.idx_identity ? k : a.idx_safe[k];
+}
 
 // LDS slice of one wave (bytes).  Layout (S = samples, e = sizeof(T)):
 //   W[64] | P[3][S] YAW[S] | D[S] | CC[S] SS[S] | D1[3][S]                        (T; every launch: 10 arrays)
@@ -97,7 +111,7 @@ __device__ __forceinline__ void clearance_chunk(const EvalArgs<T> &a, const BoxR
     const bool valid = k0 + lane < Sp;
     float px32 = 0.f, py32 = 0.f, pz32 = 0.f, exs = 0.f, eys = 0.f, ezs = 0.f, slack = 0.f;
     if (valid) {
-        const int s = LOCAL ? lane : a.idx_safe[k0 + lane];
+        const int s = LOCAL ? lane : sample_of(a, k0 + lane);
         T c, sn;
         yaw_rot(YW[s], c, sn);
         CC[lane] = c; SS[lane] = sn;
@@ -140,7 +154,7 @@ __device__ __forceinline__ void clearance_chunk(const EvalArgs<T> &a, const BoxR
             const unsigned int e = QUEUE[(qhead + lane) & 127];
             kk = (int)(e >> 24);
             bb = (int)(e & 0xffffffu);
-            const int ss = LOCAL ? kk : a.idx_safe[k0 + kk];
+            const int ss = LOCAL ? kk : sample_of(a, k0 + kk);
             const BoxRec<T> bx = boxes[bb];
             T qx = P0[ss], qy = P1[ss], qc = CC[kk], qs = SS[kk], bcx = bx.cx, bcy = bx.cy;
             if (ROT) {   // evaluate the pair in the box's own frame
@@ -250,6 +264,7 @@ __global__ void __launch_bounds__(256, MP_MIN_WAVES) eval_kernel(const EvalArgs<
         const int box_begin = __builtin_amdgcn_readfirstlane(tk.box_begin);
         const BoxRec<T> *boxes = a.boxes + box_begin;
 
+        MP_PHASE_INIT;
         // ---- waypoint table W[j][0..2] = position rows, W[j][3] = yaw controls ----
         {
             const int rows = C > Cy ? C : Cy;
@@ -285,6 +300,7 @@ __global__ void __launch_bounds__(256, MP_MIN_WAVES) eval_kernel(const EvalArgs<
         }
         wave_lds_sync();
 
+        MP_PHASE(0);  // waypoints + spline
         // ---- per-sample geometric terms, pass 1 ----
         T t_len = T(0), t_ys = T(0), t_mono = T(0), t_sched = T(0), t_curv = T(0);
         const T y0 = tk.yaw_ctrl[0], y1 = tk.yaw_ctrl[Cy - 1];
@@ -315,6 +331,7 @@ __global__ void __launch_bounds__(256, MP_MIN_WAVES) eval_kernel(const EvalArgs<
             }
         }
         wave_lds_sync();
+        MP_PHASE(1);  // pass 1
         // ---- curvature, pass 2 (second np.gradient) ----
         if ((mask & (1u << 1)) && S >= 3) {
             const T eps = T(1e-9);
@@ -359,6 +376,7 @@ __global__ void __launch_bounds__(256, MP_MIN_WAVES) eval_kernel(const EvalArgs<
             }
         }
 
+        MP_PHASE(2);  // curvature
         // ---- clearance profile d_safe ----
         int Sp = a.Sp;
         if (MODEL == 1 && PRE) {
@@ -369,7 +387,7 @@ __global__ void __launch_bounds__(256, MP_MIN_WAVES) eval_kernel(const EvalArgs<
                 ARG[k] = a.pre_arg[cand * a.Sp + k];
                 if (GRAD) {
                     T c, sn;
-                    yaw_rot(YW[a.idx_safe[k]], c, sn);
+                    yaw_rot(YW[sample_of(a, k)], c, sn);
                     CC[k] = c; SS[k] = sn;
                 }
                 if (a.dist) a.dist[cand * a.Sp + k] = d;
@@ -390,7 +408,7 @@ __global__ void __launch_bounds__(256, MP_MIN_WAVES) eval_kernel(const EvalArgs<
             }
         } else {
             for (int k = lane; k < Sp; k += 64) {
-                const int s = a.idx_safe[k];
+                const int s = sample_of(a, k);
                 int arg = -1;
                 const T d = point_distance(P0[s], P1[s], P2[s], boxes, nb, a.radius, ROT, arg);
                 Dd[k] = d;
@@ -400,13 +418,14 @@ __global__ void __launch_bounds__(256, MP_MIN_WAVES) eval_kernel(const EvalArgs<
         }
         wave_lds_sync();
         if (a.last_cond && Sp >= 2) {  // P[::k] + conditional last sample (spline_opt.py:802-805)
-            const int sa = a.idx_safe[Sp - 2], sb = S - 1;
+            const int sa = sample_of(a, Sp - 2), sb = S - 1;
             bool close = mp_abs(P0[sa] - P0[sb]) <= T(1e-8) + T(1e-5) * mp_abs(P0[sb]);
             close = close && (mp_abs(P1[sa] - P1[sb]) <= T(1e-8) + T(1e-5) * mp_abs(P1[sb]));
             close = close && (mp_abs(P2[sa] - P2[sb]) <= T(1e-8) + T(1e-5) * mp_abs(P2[sb]));
             if (close) Sp -= 1;
         }
 
+        MP_PHASE(3);  // clearance profile
         // ---- clearance terms (and d cost / d d_k) ----
         T t_safe = T(0), t_pref = T(0), t_reb = T(0), t_gc = T(0), t_gt = T(0), t_ac = T(0), t_acol = T(0);
         T mc = Lim<T>::inf();
@@ -463,6 +482,7 @@ __global__ void __launch_bounds__(256, MP_MIN_WAVES) eval_kernel(const EvalArgs<
             if (GRAD) GD[k] = gd;
         }
 
+        MP_PHASE(4);  // clearance terms
         // ---- small closed-form terms, computed redundantly by every lane ----
         T t_via = T(0), t_ydev = T(0), t_gn = T(0);
         if (mask & (1u << 10))
@@ -502,6 +522,7 @@ __global__ void __launch_bounds__(256, MP_MIN_WAVES) eval_kernel(const EvalArgs<
             }
         }
 
+        MP_PHASE(5);  // closed-form terms
         // ---- reductions over the wave and outputs ----
         T term[kNTerms];
         T jtot = T(0);
@@ -558,6 +579,7 @@ __global__ void __launch_bounds__(256, MP_MIN_WAVES) eval_kernel(const EvalArgs<
         }
 
         if (GRAD) {
+            MP_PHASE(6);  // reductions + outputs
             // (1) clearance chain: scatter d cost/d d_k * d d_k/d(P,yaw) to the sample it came from
             wave_lds_sync();
             const T DEG2RAD = T(0.017453292519943295);
@@ -565,7 +587,7 @@ __global__ void __launch_bounds__(256, MP_MIN_WAVES) eval_kernel(const EvalArgs<
                 const T gd = GD[k];
                 const int arg = ARG[k];
                 if (gd != T(0) && arg >= 0) {
-                    const int s = a.idx_safe[k];
+                    const int s = sample_of(a, k);
                     const BoxRec<T> bx = boxes[arg];
                     if (MODEL == 1) {
                         T g0, g1, g2, g3;
@@ -579,6 +601,7 @@ __global__ void __launch_bounds__(256, MP_MIN_WAVES) eval_kernel(const EvalArgs<
                     }
                 }
             }
+            MP_PHASE(7);  // grad: clearance chain
             // (2) curvature: T1 = A1 + G^T A2 (kept in D1*).  (G^T v)[s] = cm v[s-1] + c0 v[s] + cp v[s+1]
             // with the transposed np.gradient coefficients of row s (ends one-sided, inside central).
             const bool curv = (mask & 2u) && S >= 3;
@@ -594,6 +617,7 @@ __global__ void __launch_bounds__(256, MP_MIN_WAVES) eval_kernel(const EvalArgs<
                 }
             }
             wave_lds_sync();
+            MP_PHASE(8);  // grad: curvature transpose
             // (3) gather every contribution to gP[s], gyaw[s]
             for (int s = lane; s < S; s += 64) {
                 T gx = G0[s], gy = G1[s], gz = G2[s], gw = GY[s];
@@ -643,6 +667,7 @@ __global__ void __launch_bounds__(256, MP_MIN_WAVES) eval_kernel(const EvalArgs<
                 A1x[s] = gx; A1y[s] = gy; A1z[s] = gz; A2x[s] = gw;
             }
             wave_lds_sync();
+            MP_PHASE(9);  // grad: gather
             // (4) x-gradient: M^T g, one wave reduction per optimised coordinate
             T *gout = a.grad + cand * D;
             for (int j = 0; j < nf; ++j) {
@@ -667,6 +692,7 @@ __global__ void __launch_bounds__(256, MP_MIN_WAVES) eval_kernel(const EvalArgs<
                 if (lane == 0) gout[3 * nf + j] = sw;
             }
         }
+        MP_PHASE(10);  // grad: M^T g (or, cost only: reductions + outputs)
         wave_lds_sync();  // the next candidate reuses the slice
     }
 }
@@ -732,7 +758,7 @@ __global__ void __launch_bounds__(256) clearance_kernel(const EvalArgs<T> a)
         wave_lds_sync();
         const int k = k0 + lane;
         if (k < a.Sp) {   // this lane's sample, same fma chain as eval_kernel
-            const int s = a.idx_safe[k];
+            const int s = sample_of(a, k);
             const T *m = a.M + (size_t)s * C;
             T m0 = m[0];
             T px = m0 * W[0], py = m0 * W[1], pz = m0 * W[2];
