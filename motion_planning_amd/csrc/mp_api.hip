@@ -1001,6 +1001,9 @@ extern "C" int mp_debug_stats(unsigned long long *out8)
     return MP_OK;
 }
 
+#endif
+
+#ifdef MP_PHASES
 extern "C" int mp_debug_phases(unsigned long long *out16)
 {
     if (hipDeviceSynchronize() != hipSuccess) return MP_E_HIP;

@@ -13,19 +13,27 @@ namespace mp {
 #ifndef MP_MIN_WAVES
 #define MP_MIN_WAVES 3
 #endif
+// Investigation builds only (tools/clearance_stats.py, tools/phase_clock.py build them into build_ab/):
+//   -DMP_STATS   work counters of the clearance phase (contended atomics: timings of such a build mean nothing)
+//   -DMP_PHASES  per-phase cycle clocks of eval_kernel, accumulated per wave and flushed once at kernel end
 #ifdef MP_STATS
-// investigation build only (tools/ build it into build_ab/): work counters of the clearance phase
 __device__ unsigned long long g_stats[8];
 #define MP_STAT_ADD(i, v) do { if (lane == 0) atomicAdd(&g_stats[i], (unsigned long long)(v)); } while (0)
-// phase clock of eval_kernel: cycles since the previous mark are added to g_phase[i]
-__device__ unsigned long long g_phase[16];
-#define MP_PHASE_INIT unsigned long long mp_t_prev = __builtin_readcyclecounter()
-#define MP_PHASE(i) do { unsigned long long mp_t_now = __builtin_readcyclecounter(); \
-        if (lane == 0) atomicAdd(&g_phase[i], mp_t_now - mp_t_prev); mp_t_prev = mp_t_now; } while (0)
 #else
 #define MP_STAT_ADD(i, v) do { } while (0)
+#endif
+#ifdef MP_PHASES
+__device__ unsigned long long g_phase[16];
+#define MP_PHASE_DECL unsigned long long mp_ph[11] = {0}
+#define MP_PHASE_INIT unsigned long long mp_t_prev = __builtin_readcyclecounter()
+#define MP_PHASE(i) do { unsigned long long mp_t_now = __builtin_readcyclecounter(); \
+        mp_ph[i] += mp_t_now - mp_t_prev; mp_t_prev = mp_t_now; } while (0)
+#define MP_PHASE_FLUSH do { if (lane == 0) for (int mp_i = 0; mp_i < 11; ++mp_i) atomicAdd(&g_phase[mp_i], mp_ph[mp_i]); } while (0)
+#else
+#define MP_PHASE_DECL do { } while (0)
 #define MP_PHASE_INIT do { } while (0)
 #define MP_PHASE(i) do { } while (0)
+#define MP_PHASE_FLUSH do { } while (0)
 #endif
 constexpr int kMaxCtrl = 16;
 constexpr int kNTerms = 15;
@@ -248,6 +256,7 @@ __global__ void __launch_bounds__(256, MP_MIN_WAVES) eval_kernel(const EvalArgs<
     // the stencils of np.gradient multiply by these instead of dividing by du / 2du (<= 1 ulp apart)
     const T inv_du = T(1) / du, inv_h2 = T(1) / (T(2) * du);
 
+    MP_PHASE_DECL;
     for (long long cand = (long long)blockIdx.x * wpb + wib; cand < a.n; cand += (long long)gridDim.x * wpb) {
         long long tl;
         if (a.group_size > 0) {
@@ -668,33 +677,43 @@ __global__ void __launch_bounds__(256, MP_MIN_WAVES) eval_kernel(const EvalArgs<
             }
             wave_lds_sync();
             MP_PHASE(9);  // grad: gather
-            // (4) x-gradient: M^T g, one wave reduction per optimised coordinate
+            // (4) x-gradient: M^T g.  Eight outputs per pass: lane = (output o = lane / 8, sample group g = lane % 8),
+            // every lane sums its output over the samples s = g, g + 8, ... and three DPP steps add the eight groups
+            // (instead of one full wave reduction per output with all lanes on the same output).
             T *gout = a.grad + cand * D;
-            for (int j = 0; j < nf; ++j) {
-                T sx = T(0), sy = T(0), sz = T(0);
-                for (int s = lane; s < S; s += 64) {
-                    T m = a.M[(size_t)s * C + ff + j];
-                    sx += m * A1x[s]; sy += m * A1y[s]; sz += m * A1z[s];
+            const int og = lane >> 3, sg8 = lane & 7;
+            for (int o0 = 0; o0 < D; o0 += 8) {
+                const int o = o0 + og;
+                T acc = T(0);
+                if (o < D) {
+                    const bool is_pos = o < 3 * nf;
+                    const int jj = is_pos ? o / 3 : o - 3 * nf;
+                    const int comp = is_pos ? o - 3 * jj : 0;
+                    const T *V = is_pos ? A1x + comp * S : A2x;
+                    const T *Mc = is_pos ? a.M + ff + jj : a.My + 1 + jj;
+                    const int ld = is_pos ? C : Cy;
+                    for (int sidx = sg8; sidx < S; sidx += 8) acc = mp_fma(Mc[(size_t)sidx * ld], V[sidx], acc);
                 }
-                sx = wave_sum(sx); sy = wave_sum(sy); sz = wave_sum(sz);
-                if (mask & (1u << 10)) {
-                    sx += a.w[10] * T(2) * (W[4 * (ff + j) + 0] - tk.ctrl[ff + j][0]);
-                    sy += a.w[10] * T(2) * (W[4 * (ff + j) + 1] - tk.ctrl[ff + j][1]);
-                    sz += a.w[10] * T(2) * (W[4 * (ff + j) + 2] - tk.ctrl[ff + j][2]);
+                acc += dpp_mov<0xB1, 0xf, true>(acc);   // quad_perm [1,0,3,2]
+                acc += dpp_mov<0x4E, 0xf, true>(acc);   // quad_perm [2,3,0,1]
+                acc += dpp_mov<0x141, 0xf, true>(acc);  // row_half_mirror: the other quad of this group of 8
+                if (o < D && sg8 == 0) {
+                    const bool is_pos = o < 3 * nf;
+                    const int jj = is_pos ? o / 3 : o - 3 * nf;
+                    const int comp = is_pos ? o - 3 * jj : 0;
+                    if (is_pos) {
+                        if (mask & (1u << 10)) acc += a.w[10] * T(2) * (W[4 * (ff + jj) + comp] - tk.ctrl[ff + jj][comp]);
+                    } else {
+                        if (mask & (1u << 11)) acc += a.w[11] * T(2) * (W[4 * (1 + jj) + 3] - tk.yaw_ctrl[1 + jj]);
+                    }
+                    gout[o] = acc;
                 }
-                if (lane == 0) { gout[3 * j + 0] = sx; gout[3 * j + 1] = sy; gout[3 * j + 2] = sz; }
-            }
-            for (int j = 0; j < nyf; ++j) {
-                T sw = T(0);
-                for (int s = lane; s < S; s += 64) sw += a.My[(size_t)s * Cy + 1 + j] * A2x[s];
-                sw = wave_sum(sw);
-                if (mask & (1u << 11)) sw += a.w[11] * T(2) * (W[4 * (1 + j) + 3] - tk.yaw_ctrl[1 + j]);
-                if (lane == 0) gout[3 * nf + j] = sw;
             }
         }
         MP_PHASE(10);  // grad: M^T g (or, cost only: reductions + outputs)
         wave_lds_sync();  // the next candidate reuses the slice
     }
+    MP_PHASE_FLUSH;
 }
 
 // ---- split mode: the clearance profile on its own, one wave per (candidate, 64-sample chunk) --------------

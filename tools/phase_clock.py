@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Where the cycles of eval_kernel go, per phase (investigation aid; needs the -DMP_STATS build, see
+"""Where the cycles of eval_kernel go, per phase (investigation aid; needs the -DMP_PHASES build -> build_ab/libmp_phases.so, cf.
 tools/clearance_stats.py).  Cycle deltas are wall cycles of a wave (other waves interleave), so read them as shares."""
 import ctypes as C
 import sys
