@@ -420,8 +420,9 @@ int launch_eval(mp_ctx *ctx, long long n, const void *X, const int32_t *task_of,
         size_t best = 0;
         for (int w = 1; w <= 4; ++w) {
             if (per_wave * w > ctx->max_lds || (w > 1 && per_wave * w > 65536)) break;
-            // 12 = the 3 waves per SIMD the kernels' VGPR budget (__launch_bounds__(256, MP_MIN_WAVES)) allows on a CU
-            const size_t waves = std::min<size_t>(std::min<size_t>(ctx->max_lds / (per_wave * w), 16) * w, 12);
+            // VGPR budget of the kernel variant (__launch_bounds__): waves per SIMD x 4 SIMDs per CU
+            const size_t vgpr_cap = (size_t)4 * (grad != nullptr ? mp::eval_min_waves<T, true>() : mp::eval_min_waves<T, false>());
+            const size_t waves = std::min<size_t>(std::min<size_t>(ctx->max_lds / (per_wave * w), 16) * w, vgpr_cap);
             if (waves >= best) { best = waves; wpb = w; }
         }
     }

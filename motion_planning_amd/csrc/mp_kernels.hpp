@@ -226,8 +226,12 @@ __device__ __forceinline__ void clearance_chunk(const EvalArgs<T> &a, const BoxR
 
 // ROT: the scene holds yaw-rotated static boxes (a separate instantiation keeps the axis-aligned code as it was)
 // PRE: split mode, the clearance profile comes from clearance_kernel (box model only)
+// Waves per SIMD the register budget is sized for: the fp64 gradient kernels need ~168 VGPRs (3 waves), every fp32
+// kernel and the fp64 cost-only kernels fit 128 (4 waves; the CEM populations run on those).
+template <typename T, bool GRAD> constexpr int eval_min_waves() { return (sizeof(T) == 8 && GRAD) ? MP_MIN_WAVES : MP_MIN_WAVES + 1; }
+
 template <typename T, int MODEL, bool GRAD, bool ROT, bool PRE>
-__global__ void __launch_bounds__(256, MP_MIN_WAVES) eval_kernel(const EvalArgs<T> a)
+__global__ void __launch_bounds__(256, (eval_min_waves<T, GRAD>())) eval_kernel(const EvalArgs<T> a)
 {
     extern __shared__ __align__(16) unsigned char smem_raw[];
     const int lane = threadIdx.x & 63;
