@@ -40,6 +40,55 @@ __device__ __forceinline__ double mp_min(double a, double b) { return __builtin_
 __device__ __forceinline__ float mp_min(float a, float b) { return __builtin_fminf(a, b); }
 
 template <typename T> __device__ __forceinline__ T sgn(T v) { return v < T(0) ? T(-1) : T(1); }
+// sqrt(q) and 1/sqrt(q) together, from the hardware reciprocal-square-root estimate and Newton steps
+// (coupled Goldschmidt iteration): ~47 SIMD cycles per wave in fp64 against 97 for the correctly rounded sqrt plus
+// 71 for a division (tools/micro/f64_ops.hip).  Results are within ~1 ulp, NOT correctly rounded: used only where
+// the parity bar is a tolerance (cost terms, gradient), never on the path to the clearances and flags.
+// Zero, denormal-range and non-finite inputs take the exact path (wave-uniform branch, rare).
+__device__ __forceinline__ void sqrt_rsqrt(double q, double &s, double &inv)
+{
+    if (__builtin_amdgcn_ballot_w64(!(q > 1e-280 && q < 1e280))) {
+        s = __builtin_sqrt(q);
+        inv = 1.0 / s;
+        return;
+    }
+    const double y = __builtin_amdgcn_rsq(q);
+    double g = q * y, h = 0.5 * y;
+    double e = __builtin_fma(-h, g, 0.5);
+    g = __builtin_fma(g, e, g); h = __builtin_fma(h, e, h);
+    e = __builtin_fma(-h, g, 0.5);
+    g = __builtin_fma(g, e, g); h = __builtin_fma(h, e, h);
+    s = g; inv = h + h;
+}
+__device__ __forceinline__ void sqrt_rsqrt(float q, float &s, float &inv)
+{
+    if (__builtin_amdgcn_ballot_w64(!(q > 1e-30f && q < 1e30f))) {
+        s = __builtin_sqrtf(q);
+        inv = 1.0f / s;
+        return;
+    }
+    const float y = __builtin_amdgcn_rsqf(q);
+    float g = q * y, h = 0.5f * y;
+    const float e = __builtin_fmaf(-h, g, 0.5f);
+    g = __builtin_fmaf(g, e, g); h = __builtin_fmaf(h, e, h);
+    s = g; inv = h + h;
+}
+// 1/b to ~1 ulp (reciprocal estimate + Newton); same restriction as sqrt_rsqrt
+__device__ __forceinline__ double fast_rcp(double b)
+{
+    double x = __builtin_amdgcn_rcp(b);
+    double e = __builtin_fma(-b, x, 1.0);
+    x = __builtin_fma(x, e, x);
+    e = __builtin_fma(-b, x, 1.0);
+    return __builtin_fma(x, e, x);
+}
+__device__ __forceinline__ float fast_rcp(float b)
+{
+    float x = __builtin_amdgcn_rcpf(b);
+    const float e = __builtin_fmaf(-b, x, 1.0f);
+    return __builtin_fmaf(x, e, x);
+}
+
 // np.maximum(0, v): NaN-propagating
 template <typename T> __device__ __forceinline__ T npmax0(T v) { return !(v <= T(0)) ? v : T(0); }
 
@@ -362,9 +411,10 @@ __device__ __forceinline__ void pair_grad_local(const Pose<T> &p, T ax, T ay, T 
         }
         if (!xy_sep) dxy2 = T(0);
         T zs = mp_max(o.gz, T(0));
-        T d = mp_sqrt(mp_fma(zs, zs, dxy2));
-        if (!(d > T(0))) return;
-        const T inv_d = T(1) / d;
+        const T d2 = mp_fma(zs, zs, dxy2);
+        if (!(d2 > T(0))) return;
+        T d, inv_d;
+        sqrt_rsqrt(d2, d, inv_d);
         if (o.gz > T(0)) g2 = sgn(o.dz) * o.gz * inv_d;
         if (!xy_sep) return;
         if (f < 4) {
@@ -461,9 +511,11 @@ __device__ __forceinline__ void point_grad(T px, T py, T pz, const BoxRec<T> bx,
     g0 = g1 = g2 = T(0);
     if (qx > T(0) || qy > T(0) || qz > T(0)) {
         T mx = mp_max(qx, T(0)), my = mp_max(qy, T(0)), mz = mp_max(qz, T(0));
-        T d = mp_sqrt(mp_fma(mz, mz, mp_fma(my, my, mx * mx)));
-        if (!(d > T(0))) return;
-        g0 = sgn(ex) * mx / d; g1 = sgn(ey) * my / d; g2 = sgn(ez) * mz / d;
+        const T d2 = mp_fma(mz, mz, mp_fma(my, my, mx * mx));
+        if (!(d2 > T(0))) return;
+        T d, inv_d;
+        sqrt_rsqrt(d2, d, inv_d);
+        g0 = sgn(ex) * mx * inv_d; g1 = sgn(ey) * my * inv_d; g2 = sgn(ez) * mz * inv_d;
     } else {
         int a = 0;
         T best = qx;

@@ -321,9 +321,10 @@ __global__ void __launch_bounds__(256, (eval_min_waves<T, GRAD>())) eval_kernel(
             const T px = P0[s], py = P1[s], pz = P2[s], yw = YW[s];
             if (s + 1 < S) {
                 T ex = P0[s + 1] - px, ey = P1[s + 1] - py, ez = P2[s + 1] - pz;
-                T n = mp_sqrt(ex * ex + ey * ey + ez * ez);
+                T n, inv_n;
+                sqrt_rsqrt(ex * ex + ey * ey + ez * ez, n, inv_n);
                 t_len += n;
-                if (GRAD) SEGW[s] = n > T(0) ? a.w[0] / n : T(0);  // w_len / |segment s|, reused by the reverse sweep
+                if (GRAD) SEGW[s] = n > T(0) ? a.w[0] * inv_n : T(0);  // w_len / |segment s|, reused by the reverse sweep
                 T dy = YW[s + 1] - yw;
                 T e = npmax0(tk.yaw_inc ? -dy : dy);
                 t_mono += e * e;
@@ -353,15 +354,14 @@ __global__ void __launch_bounds__(256, (eval_min_waves<T, GRAD>())) eval_kernel(
                 const int lo = s == 0 ? 0 : s - 1, hi = s == S - 1 ? s : s + 1;
                 const T sc = (s == 0 || s == S - 1) ? inv_du : inv_h2;
                 const T v2x = (D1x[hi] - D1x[lo]) * sc, v2y = (D1y[hi] - D1y[lo]) * sc, v2z = (D1z[hi] - D1z[lo]) * sc;
-                T speed = mp_sqrt(v1x * v1x + v1y * v1y + v1z * v1z);
+                T speed, inv_speed;
+                sqrt_rsqrt(v1x * v1x + v1y * v1y + v1z * v1z, speed, inv_speed);
                 T cx = v1y * v2z - v1z * v2y, cy = v1z * v2x - v1x * v2z, cz = v1x * v2y - v1y * v2x;
                 T cn2 = cx * cx + cy * cy + cz * cz;
-                T cn = mp_sqrt(cn2);
-                T sp = speed > eps ? speed : eps;
-                T inv_sp = T(1) / sp;
+                // kappa^2 speed = |c|^2 speed / max(speed, eps)^6 (|c| itself is never needed)
+                const T inv_sp = speed > eps ? inv_speed : T(1e9);
                 T inv_sp3 = inv_sp * inv_sp * inv_sp;
-                T kappa = cn * inv_sp3;
-                t_curv += (kappa * kappa) * speed;
+                t_curv += (cn2 * (inv_sp3 * inv_sp3)) * speed;
                 if (GRAD) {
                     // f = |c|^2 speed / sp^6 with c = d1 x d2; adjoints of d1 and d2
                     const T inv_sp6 = inv_sp3 * inv_sp3;
@@ -374,7 +374,7 @@ __global__ void __launch_bounds__(256, (eval_min_waves<T, GRAD>())) eval_kernel(
                         gs = gs + T(-6) * gs;  // explicit + through sp (= speed)
                         q = k * gs * inv_sp;
                     } else if (speed > T(0)) {
-                        q = k * gs / speed;
+                        q = k * gs * inv_speed;
                     }
                     A1x[s] = v2y * gcz - v2z * gcy + q * v1x;
                     A1y[s] = v2z * gcx - v2x * gcz + q * v1y;
@@ -515,9 +515,10 @@ __global__ void __launch_bounds__(256, (eval_min_waves<T, GRAD>())) eval_kernel(
         gn_first = gn_first < 0 ? 0 : gn_first;
         if ((mask & (1u << 14)) && tk.has_normal && S >= 3 && gn_first < S - 1) {
             T vx = P0[S - 1] - P0[gn_first], vy = P1[S - 1] - P1[gn_first], vz = P2[S - 1] - P2[gn_first];
-            T n = mp_sqrt(vx * vx + vy * vy + vz * vz);
+            T n, inv_n;
+            sqrt_rsqrt(vx * vx + vy * vy + vz * vz, n, inv_n);
             if (!(n < T(1e-12))) {
-                T ux = vx / n, uy = vy / n, uz = vz / n;
+                T ux = vx * inv_n, uy = vy * inv_n, uz = vz * inv_n;
                 if (ux != T(0) || uy != T(0) || uz != T(0)) {
                     const T sx = tk.normal[0], sy = tk.normal[1], sz = tk.normal[2];
                     T c = ux * -sx + uy * -sy + uz * -sz;
@@ -527,9 +528,9 @@ __global__ void __launch_bounds__(256, (eval_min_waves<T, GRAD>())) eval_kernel(
                     if (GRAD && c > T(-1) && c < T(1)) {
                         T us = ux * sx + uy * sy + uz * sz;
                         T k = a.w[14] * T(-2) * e;
-                        gnx = k * -(sx - ux * us) / n;
-                        gny = k * -(sy - uy * us) / n;
-                        gnz = k * -(sz - uz * us) / n;
+                        gnx = k * -(sx - ux * us) * inv_n;
+                        gny = k * -(sy - uy * us) * inv_n;
+                        gnz = k * -(sz - uz * us) * inv_n;
                     }
                 }
             }
