@@ -302,42 +302,37 @@ template <typename T> int upload_problem(mp_ctx *ctx, const mp_task *tasks)
                 }
                 const int sb0 = (int)sb.size(), g0 = (int)gr.size();
                 const int gsz = cnt >= kGroupMin ? kGroup : std::max(cnt, 1);
+                auto down = [](double v) { float f = (float)v; return (double)f > v ? std::nextafter(f, -INFINITY) : f; };
+                auto up = [](double v) { float f = (float)v; return (double)f < v ? std::nextafter(f, INFINITY) : f; };
+                std::vector<std::array<float, 3>> centre((size_t)cnt);
                 for (int k = 0; k < cnt; ++k) {
                     const double *r = &ctx->h_boxes[(size_t)(b0 + order[k]) * 6];
-                    sb.push_back(mp::BoxRec32{(float)r[0], (float)r[1], (float)r[2], (float)r[3], (float)r[4], (float)r[5],
-                                              as_float(order[k]), 0.f});
+                    sb.push_back(mp::BoxRec32{down(r[0] - r[3]), down(r[1] - r[4]), down(r[2] - r[5]), up(r[0] + r[3]), up(r[1] + r[4]),
+                                              up(r[2] + r[5]), as_float(order[k]), 0.f});
+                    centre[(size_t)k] = {(float)r[0], (float)r[1], (float)r[2]};
                 }
                 for (int k = 0; k < cnt; k += gsz) {
                     const int m = std::min(gsz, cnt - k);
-                    float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+                    mp::BoxRec32 g{INFINITY, INFINITY, INFINITY, -INFINITY, -INFINITY, -INFINITY, 0.f, 0.f};
                     for (int q = 0; q < m; ++q) {
                         const mp::BoxRec32 &r = sb[(size_t)sb0 + k + q];
-                        const float c[3] = {r.cx, r.cy, r.cz}, h[3] = {r.hx, r.hy, r.hz};
-                        for (int a = 0; a < 3; ++a) {
-                            lo[a] = std::min(lo[a], std::nextafter(c[a] - h[a], -INFINITY));
-                            hi[a] = std::max(hi[a], std::nextafter(c[a] + h[a], INFINITY));
-                        }
-                    }
-                    mp::BoxRec32 g{};
-                    float *gc = &g.cx, *gh = &g.hx;
-                    for (int a = 0; a < 3; ++a) {
-                        gc[a] = 0.5f * (lo[a] + hi[a]);
-                        // half extent rounded up so that [c-h, c+h] contains [lo, hi] despite the rounding of c
-                        gh[a] = std::nextafter(std::max(hi[a] - gc[a], gc[a] - lo[a]), INFINITY);
+                        g.lox = std::min(g.lox, r.lox); g.loy = std::min(g.loy, r.loy); g.loz = std::min(g.loz, r.loz);
+                        g.hix = std::max(g.hix, r.hix); g.hiy = std::max(g.hiy, r.hiy); g.hiz = std::max(g.hiz, r.hiz);
                     }
                     g.pad0 = as_float(k);   // first sorted index, relative to sbox_begin
                     g.pad1 = as_float(m);
                     gr.push_back(g);
                     // representative: the member whose centre is nearest to the centre of the group's AABB
+                    const float gcx = 0.5f * (g.lox + g.hix), gcy = 0.5f * (g.loy + g.hiy), gcz = 0.5f * (g.loz + g.hiz);
                     int best = 0;
                     float bd = INFINITY;
                     for (int q = 0; q < m; ++q) {
-                        const mp::BoxRec32 &r = sb[(size_t)sb0 + k + q];
-                        const float d2 = (r.cx - g.cx) * (r.cx - g.cx) + (r.cy - g.cy) * (r.cy - g.cy) + (r.cz - g.cz) * (r.cz - g.cz);
+                        const auto &c3 = centre[(size_t)k + q];
+                        const float d2 = (c3[0] - gcx) * (c3[0] - gcx) + (c3[1] - gcy) * (c3[1] - gcy) + (c3[2] - gcz) * (c3[2] - gcz);
                         if (d2 < bd) { bd = d2; best = q; }
                     }
                     mp::BoxRec32 rep{};
-                    if (m > 0) { rep.cx = sb[(size_t)sb0 + k + best].cx; rep.cy = sb[(size_t)sb0 + k + best].cy; rep.cz = sb[(size_t)sb0 + k + best].cz; }
+                    if (m > 0) { rep.lox = centre[(size_t)k + best][0]; rep.loy = centre[(size_t)k + best][1]; rep.loz = centre[(size_t)k + best][2]; }
                     gr.push_back(rep);
                 }
                 done.push_back({b0, cnt, sb0, g0 / 2, ((int)gr.size() - g0) / 2});

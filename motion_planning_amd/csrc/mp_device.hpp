@@ -333,28 +333,29 @@ __device__ __forceinline__ unsigned long long pair_key(const Pose<T> &p, T ax, T
     return separated ? ks : kp;
 }
 
-// fp32 record of a box for the bound pass
-struct BoxRec32 { float cx, cy, cz, hx, hy, hz, pad0, pad1; };
+// fp32 record of a box for the bound pass: the box's world AABB as [lo, hi] per axis (rounded outwards);
+// pad0 / pad1 carry integers (original index; for group records first / count).  A representative record
+// keeps a centre in lox, loy, loz.
+struct BoxRec32 { float lox, loy, loz, hix, hiy, hiz, pad0, pad1; };
 
 __device__ __forceinline__ BoxRec32 load_box32_uniform(const BoxRec32 *boxes, int i)
 {
     typedef const float __attribute__((address_space(4))) *CPtr;
     CPtr p = (CPtr)(unsigned long long)(boxes + i);
     BoxRec32 r;
-    r.cx = p[0]; r.cy = p[1]; r.cz = p[2]; r.hx = p[3]; r.hy = p[4]; r.hz = p[5];
+    r.lox = p[0]; r.loy = p[1]; r.loz = p[2]; r.hix = p[3]; r.hiy = p[4]; r.hiz = p[5];
     r.pad0 = p[6]; r.pad1 = p[7];
     return r;
 }
 
-// Conservative lower bound (fp32) of the squared distance between the mover's world AABB and a
-// box: the three world-axis SAT gaps, each deflated by `slack` (folded into ex/ey/ez by the
-// caller) so that fp32 rounding can never lift the bound above the exactly evaluated value.
-__device__ __forceinline__ float aabb_lb2(float px, float py, float pz, float exs, float eys, float ezs, const BoxRec32 &b)
+// Conservative lower bound (fp32) of the squared distance between the mover's world AABB [mlo, mhi] (already
+// inflated by `slack`, so that fp32 rounding can never lift the bound above the exactly evaluated value) and a
+// box's AABB: per axis max(b.lo - m.hi, m.lo - b.hi, 0), two subtractions and one v_max3_f32.
+__device__ __forceinline__ float aabb_lb2(float mlox, float mloy, float mloz, float mhix, float mhiy, float mhiz, const BoxRec32 &b)
 {
-    float qx = __builtin_fabsf(px - b.cx) - (b.hx + exs);
-    float qy = __builtin_fabsf(py - b.cy) - (b.hy + eys);
-    float qz = __builtin_fabsf(pz - b.cz) - (b.hz + ezs);
-    float mx = __builtin_fmaxf(qx, 0.f), my = __builtin_fmaxf(qy, 0.f), mz = __builtin_fmaxf(qz, 0.f);
+    const float mx = __builtin_fmaxf(__builtin_fmaxf(b.lox - mhix, mlox - b.hix), 0.f);
+    const float my = __builtin_fmaxf(__builtin_fmaxf(b.loy - mhiy, mloy - b.hiy), 0.f);
+    const float mz = __builtin_fmaxf(__builtin_fmaxf(b.loz - mhiz, mloz - b.hiz), 0.f);
     return __builtin_fmaf(mz, mz, __builtin_fmaf(my, my, mx * mx));
 }
 

@@ -133,6 +133,8 @@ __device__ __forceinline__ void clearance_chunk(const EvalArgs<T> &a, const BoxR
         eys = __builtin_fmaf(c32, ay32, s32 * ax32) + slack;
         ezs = az32 + slack;
     }
+    // the mover's inflated world AABB (the rounding of these six operations is far inside the slack)
+    const float mlox = px32 - exs, mloy = py32 - eys, mloz = pz32 - ezs, mhix = px32 + exs, mhiy = py32 + eys, mhiz = pz32 + ezs;
     float U32 = __builtin_huge_valf();
     int qhead = 0, qcount = 0;  // wave-uniform
     MP_STAT_ADD(0, 1);
@@ -144,8 +146,8 @@ __device__ __forceinline__ void clearance_chunk(const EvalArgs<T> &a, const BoxR
         float ub = __builtin_huge_valf();
         for (int g = 0; g < ngroups; ++g) {
             const BoxRec32 rep = load_box32_uniform(groups, 2 * g + 1);
-            const float dx = __builtin_fabsf(px32 - rep.cx) + slack, dy = __builtin_fabsf(py32 - rep.cy) + slack,
-                        dz = __builtin_fabsf(pz32 - rep.cz) + slack;
+            const float dx = __builtin_fabsf(px32 - rep.lox) + slack, dy = __builtin_fabsf(py32 - rep.loy) + slack,
+                        dz = __builtin_fabsf(pz32 - rep.loz) + slack;
             ub = __builtin_fminf(ub, __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx)));
         }
         U32 = ub * (1.0f + 4e-6f);
@@ -195,7 +197,7 @@ __device__ __forceinline__ void clearance_chunk(const EvalArgs<T> &a, const BoxR
         const BoxRec32 grp = load_box32_uniform(groups, 2 * g);
         const int gfirst = __float_as_int(grp.pad0), gcnt = __float_as_int(grp.pad1);
         if (ngroups > 1) {
-            const float lbg = aabb_lb2(px32, py32, pz32, exs, eys, ezs, grp);
+            const float lbg = aabb_lb2(mlox, mloy, mloz, mhix, mhiy, mhiz, grp);
             if (!__builtin_amdgcn_ballot_w64(valid && (lbg <= U32))) continue;
         }
         MP_STAT_ADD(1, 1); MP_STAT_ADD(2, gcnt);
@@ -203,7 +205,7 @@ __device__ __forceinline__ void clearance_chunk(const EvalArgs<T> &a, const BoxR
         for (int i = 0; i < gcnt; ++i) {
             const BoxRec32 bx = nxt;
             nxt = load_box32_uniform(boxes32, gfirst + (i + 1 < gcnt ? i + 1 : i));
-            const float lb2 = aabb_lb2(px32, py32, pz32, exs, eys, ezs, bx);
+            const float lb2 = aabb_lb2(mlox, mloy, mloz, mhix, mhiy, mhiz, bx);
             const bool need = valid && (lb2 <= U32);
             const unsigned long long m = __builtin_amdgcn_ballot_w64(need);
             if (m) {
