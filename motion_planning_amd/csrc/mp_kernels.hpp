@@ -135,7 +135,9 @@ __device__ __forceinline__ void clearance_chunk(const EvalArgs<T> &a, const BoxR
     }
     // the mover's inflated world AABB (the rounding of these six operations is far inside the slack)
     const float mlox = px32 - exs, mloy = py32 - eys, mloz = pz32 - ezs, mhix = px32 + exs, mhiy = py32 + eys, mhiz = pz32 + ezs;
-    float U32 = __builtin_huge_valf();
+    // running upper bound of the lane's squared clearance; -1 on lanes without a sample, so that `lb2 <= U32`
+    // alone (one v_cmp, whose result is the ballot) says whether the lane needs a pair
+    float U32 = valid ? __builtin_huge_valf() : -1.0f;
     int qhead = 0, qcount = 0;  // wave-uniform
     MP_STAT_ADD(0, 1);
     if (SEED && ngroups > 1) {
@@ -150,7 +152,7 @@ __device__ __forceinline__ void clearance_chunk(const EvalArgs<T> &a, const BoxR
                         dz = __builtin_fabsf(pz32 - rep.loz) + slack;
             ub = __builtin_fminf(ub, __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx)));
         }
-        U32 = ub * (1.0f + 4e-6f);
+        if (valid) U32 = ub * (1.0f + 4e-6f);
     }
 
     // exact evaluation of up to 64 queued (sample, box) pairs, one per lane
@@ -198,7 +200,7 @@ __device__ __forceinline__ void clearance_chunk(const EvalArgs<T> &a, const BoxR
         const int gfirst = __float_as_int(grp.pad0), gcnt = __float_as_int(grp.pad1);
         if (ngroups > 1) {
             const float lbg = aabb_lb2(mlox, mloy, mloz, mhix, mhiy, mhiz, grp);
-            if (!__builtin_amdgcn_ballot_w64(valid && (lbg <= U32))) continue;
+            if (!__builtin_amdgcn_ballot_w64(lbg <= U32)) continue;
         }
         MP_STAT_ADD(1, 1); MP_STAT_ADD(2, gcnt);
         BoxRec32 nxt = load_box32_uniform(boxes32, gfirst);
@@ -206,7 +208,7 @@ __device__ __forceinline__ void clearance_chunk(const EvalArgs<T> &a, const BoxR
             const BoxRec32 bx = nxt;
             nxt = load_box32_uniform(boxes32, gfirst + (i + 1 < gcnt ? i + 1 : i));
             const float lb2 = aabb_lb2(mlox, mloy, mloz, mhix, mhiy, mhiz, bx);
-            const bool need = valid && (lb2 <= U32);
+            const bool need = lb2 <= U32;
             const unsigned long long m = __builtin_amdgcn_ballot_w64(need);
             if (m) {
                 if (need) {
