@@ -269,25 +269,43 @@ template <typename T> int upload_problem(mp_ctx *ctx, const mp_task *tasks)
     {
         constexpr int kGroup = 16, kGroupMin = 128;
         std::vector<mp::BoxRec32> sb, gr;
-        std::vector<std::array<int, 5>> done;  // begin, count, sbox_begin, group_begin, group_count
+        std::vector<std::array<int, 6>> done;  // begin, count, sbox_begin, group_begin, group_count, n_wide
         auto as_float = [](int v) { float f; std::memcpy(&f, &v, 4); return f; };
         for (int i = 0; i < ctx->n_tasks; ++i) {
-            const int b0 = tasks[i].box_begin, cnt = tasks[i].box_count;
-            const std::array<int, 5> *hit = nullptr;
+            const int b0 = tasks[i].box_begin;
+            int cnt = tasks[i].box_count;
+            const std::array<int, 6> *hit = nullptr;
             for (const auto &d : done)
                 if (d[0] == b0 && d[1] == cnt) { hit = &d; break; }
             if (!hit) {
-                std::vector<int> order(cnt);
-                for (int k = 0; k < cnt; ++k) order[k] = k;
+                // One "wide" box per range (a table, a floor: footprint at least twice the mover's circumradius each way,
+                // the largest one) goes first, outside the groups: the kernel settles its z-separated pairs without an
+                // exact evaluation (clearance_chunk).  Axis-aligned scenes and the box model only.
+                int wide = -1;
+                if (c.model == MP_MODEL_BOX && !ctx->has_rot) {
+                    const double rr = 2.0 * std::sqrt(c.half_extents[0] * c.half_extents[0] + c.half_extents[1] * c.half_extents[1]);
+                    double best_area = 0.0;
+                    for (int k = 0; k < cnt; ++k) {
+                        const double *r = &ctx->h_boxes[(size_t)(b0 + k) * 6];
+                        if (rr > 0.0 && r[3] >= rr && r[4] >= rr && r[3] * r[4] > best_area) { best_area = r[3] * r[4]; wide = k; }
+                    }
+                }
+                const int n_wide = wide >= 0 ? 1 : 0;
+                std::vector<int> order;
+                order.reserve((size_t)cnt);
+                for (int k = 0; k < cnt; ++k)
+                    if (k != wide) order.push_back(k);
+                const int cnt_all = cnt;
+                cnt -= n_wide;   // from here on: the boxes that go through the sorted / grouped sweep
                 if (cnt >= kGroupMin) {
                     double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
-                    for (int k = 0; k < cnt; ++k)
+                    for (int k : order)
                         for (int a = 0; a < 3; ++a) {
                             lo[a] = std::min(lo[a], ctx->h_boxes[(size_t)(b0 + k) * 6 + a]);
                             hi[a] = std::max(hi[a], ctx->h_boxes[(size_t)(b0 + k) * 6 + a]);
                         }
-                    std::vector<unsigned long long> code(cnt);
-                    for (int k = 0; k < cnt; ++k) {
+                    std::vector<unsigned long long> code((size_t)cnt_all, 0ull);
+                    for (int k : order) {
                         unsigned long long c = 0;
                         unsigned q[3];
                         for (int a = 0; a < 3; ++a) {
@@ -296,7 +314,7 @@ template <typename T> int upload_problem(mp_ctx *ctx, const mp_task *tasks)
                         }
                         for (int bit = 9; bit >= 0; --bit)
                             for (int a = 0; a < 3; ++a) c = (c << 1) | ((q[a] >> bit) & 1u);
-                        code[k] = c;
+                        code[(size_t)k] = c;
                     }
                     std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return code[x] < code[y]; });
                 }
@@ -304,6 +322,13 @@ template <typename T> int upload_problem(mp_ctx *ctx, const mp_task *tasks)
                 const int gsz = cnt >= kGroupMin ? kGroup : std::max(cnt, 1);
                 auto down = [](double v) { float f = (float)v; return (double)f > v ? std::nextafter(f, -INFINITY) : f; };
                 auto up = [](double v) { float f = (float)v; return (double)f < v ? std::nextafter(f, INFINITY) : f; };
+                auto record = [&](int orig) {
+                    const double *r = &ctx->h_boxes[(size_t)(b0 + orig) * 6];
+                    return mp::BoxRec32{down(r[0] - r[3]), down(r[1] - r[4]), down(r[2] - r[5]), up(r[0] + r[3]), up(r[1] + r[4]),
+                                        up(r[2] + r[5]), as_float(orig), 0.f};
+                };
+                if (n_wide) sb.push_back(record(wide));   // record 0 of the range
+                const int sbr = (int)sb.size();            // first record of the sorted rest
                 std::vector<std::array<float, 3>> centre((size_t)cnt);
                 for (int k = 0; k < cnt; ++k) {
                     const double *r = &ctx->h_boxes[(size_t)(b0 + order[k]) * 6];
@@ -315,11 +340,11 @@ template <typename T> int upload_problem(mp_ctx *ctx, const mp_task *tasks)
                     const int m = std::min(gsz, cnt - k);
                     mp::BoxRec32 g{INFINITY, INFINITY, INFINITY, -INFINITY, -INFINITY, -INFINITY, 0.f, 0.f};
                     for (int q = 0; q < m; ++q) {
-                        const mp::BoxRec32 &r = sb[(size_t)sb0 + k + q];
+                        const mp::BoxRec32 &r = sb[(size_t)sbr + k + q];
                         g.lox = std::min(g.lox, r.lox); g.loy = std::min(g.loy, r.loy); g.loz = std::min(g.loz, r.loz);
                         g.hix = std::max(g.hix, r.hix); g.hiy = std::max(g.hiy, r.hiy); g.hiz = std::max(g.hiz, r.hiz);
                     }
-                    g.pad0 = as_float(k);   // first sorted index, relative to sbox_begin
+                    g.pad0 = as_float(k + n_wide);   // first record of the group, relative to sbox_begin
                     g.pad1 = as_float(m);
                     gr.push_back(g);
                     // representative: the member whose centre is nearest to the centre of the group's AABB
@@ -335,13 +360,13 @@ template <typename T> int upload_problem(mp_ctx *ctx, const mp_task *tasks)
                     if (m > 0) { rep.lox = centre[(size_t)k + best][0]; rep.loy = centre[(size_t)k + best][1]; rep.loz = centre[(size_t)k + best][2]; }
                     gr.push_back(rep);
                 }
-                done.push_back({b0, cnt, sb0, g0 / 2, ((int)gr.size() - g0) / 2});
+                done.push_back({b0, cnt_all, sb0, g0 / 2, ((int)gr.size() - g0) / 2, n_wide});
                 hit = &done.back();
             }
             dt[i].sbox_begin = (*hit)[2];
             dt[i].group_begin = (*hit)[3];
             dt[i].group_count = (*hit)[4];
-            dt[i].pad = 0;
+            dt[i].n_wide = (*hit)[5];
         }
         if ((rc = upload(ctx, ctx->boxes32, sb.data(), sb.size() * sizeof(mp::BoxRec32)))) return rc;
         if ((rc = upload(ctx, ctx->groups, gr.data(), gr.size() * sizeof(mp::BoxRec32)))) return rc;

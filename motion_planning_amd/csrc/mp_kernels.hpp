@@ -46,7 +46,7 @@ template <typename T> struct DevTask {
     int sbox_begin;    // first record of this task's spatially sorted fp32 table (sboxes32)
     int group_begin;   // first group of this task in the group table (records 2*group_begin ...)
     int group_count;   // groups of kGroupSize consecutive sorted boxes (1 group: no group test)
-    int pad;
+    int n_wide;        // 1: record 0 of the sorted table is a wide box handled before the sweep (clearance_chunk)
 };
 
 template <typename T> struct EvalArgs {
@@ -110,7 +110,7 @@ __host__ __device__ inline int lds_bytes_per_wave(int S, int e, bool grad)
 // (-1: none) and CC/SS the (cos, sin) of the sample's yaw.
 template <typename T, bool ROT, bool LOCAL, bool SEED>
 __device__ __forceinline__ void clearance_chunk(const EvalArgs<T> &a, const BoxRec<T> *boxes, const BoxRec32 *boxes32,
-                                                const BoxRec32 *groups, int ngroups, int lane, int k0, int Sp, const T *P0,
+                                                const BoxRec32 *groups, int ngroups, int n_wide, int lane, int k0, int Sp, const T *P0,
                                                 const T *P1, const T *P2, const T *YW, T *CC, T *SS,
                                                 unsigned long long *MINKEY, int *ARG, unsigned int *QUEUE)
 {
@@ -190,8 +190,36 @@ __device__ __forceinline__ void clearance_chunk(const EvalArgs<T> &a, const BoxR
         wave_lds_sync();
         if (win) atomicMin(&ARG[kk], bb);  // ties: lowest box index, like a first-minimum scan
         wave_lds_sync();
-        if (valid) U32 = (float)key_to_sep2<T>(MINKEY[lane]) * (1.0f + 4e-6f);
+        if (valid) U32 = __builtin_fminf(U32, (float)key_to_sep2<T>(MINKEY[lane]) * (1.0f + 4e-6f));   // never above the seed
     };
+
+    // Wide box first (a table, a floor; chosen on the host, axis-aligned scenes only, record 0 of the table).  Where
+    // the mover's centre lies over its footprint the two footprints overlap for certain (every 2-D SAT gap is at most
+    // minus the mover's smaller half extent), so with a positive z gap the pair value is gz^2, computed exactly as
+    // pair_key would, and the lane settles the pair on its own sample slot; the other lanes queue it as usual
+    // (at most 64 entries: no drain needed here).
+    if (!ROT && n_wide > 0) {
+        const BoxRec32 bx = load_box32_uniform(boxes32, 0);
+        const int bi = __float_as_int(bx.pad0);
+        const BoxRec<T> eb = load_box_uniform(boxes, bi);
+        bool need = aabb_lb2(mlox, mloy, mloz, mhix, mhiy, mhiz, bx) <= U32;
+        if (need && a.ax > T(1e-3) && a.ay > T(1e-3)) {
+            const int sw = LOCAL ? lane : sample_of(a, k0 + lane);
+            const T gz = mp_abs(P2[sw] - eb.cz) - (a.az + eb.hz);
+            if (mp_abs(P0[sw] - eb.cx) <= eb.hx && mp_abs(P1[sw] - eb.cy) <= eb.hy && gz > T(0)) {
+                MINKEY[lane] = kSepBit | Key<T>::bits(mp_fma(gz, gz, T(0)));   // the slot is still at its initial value
+                ARG[lane] = bi;
+                U32 = __builtin_fminf(U32, (float)key_to_sep2<T>(MINKEY[lane]) * (1.0f + 4e-6f));
+                need = false;
+            }
+        }
+        const unsigned long long m = __builtin_amdgcn_ballot_w64(need);
+        if (need) {
+            const int pos = __builtin_amdgcn_mbcnt_hi((unsigned int)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)m, 0u));
+            QUEUE[pos & 127] = ((unsigned int)lane << 24) | (unsigned int)bi;
+        }
+        qcount = __builtin_popcountll(m);
+    }
 
     // Bound pass over the task's boxes in sorted order.  With several groups a whole group
     // is skipped when no lane of the wave can be closer to its AABB than its current minimum.
@@ -413,8 +441,9 @@ __global__ void __launch_bounds__(256, (eval_min_waves<T, GRAD>())) eval_kernel(
             const BoxRec32 *boxes32 = a.boxes32 + __builtin_amdgcn_readfirstlane(tk.sbox_begin);
             const BoxRec32 *groups = a.groups + 2 * __builtin_amdgcn_readfirstlane(tk.group_begin);
             const int ngroups = __builtin_amdgcn_readfirstlane(tk.group_count);
+            const int n_wide = __builtin_amdgcn_readfirstlane(tk.n_wide);
             for (int k0 = 0; k0 < Sp; k0 += 64) {
-                clearance_chunk<T, ROT, false, false>(a, boxes, boxes32, groups, ngroups, lane, k0, Sp, P0, P1, P2, YW, CC + k0, SS + k0,
+                clearance_chunk<T, ROT, false, false>(a, boxes, boxes32, groups, ngroups, n_wide, lane, k0, Sp, P0, P1, P2, YW, CC + k0, SS + k0,
                                                MINKEY + k0, ARG + k0, QUEUE);
                 const int k = k0 + lane;
                 if (k < Sp) {
@@ -770,6 +799,7 @@ __global__ void __launch_bounds__(256) clearance_kernel(const EvalArgs<T> a)
         const BoxRec32 *boxes32 = a.boxes32 + __builtin_amdgcn_readfirstlane(tk.sbox_begin);
         const BoxRec32 *groups = a.groups + 2 * __builtin_amdgcn_readfirstlane(tk.group_begin);
         const int ngroups = __builtin_amdgcn_readfirstlane(tk.group_count);
+        const int n_wide = __builtin_amdgcn_readfirstlane(tk.n_wide);
         {   // waypoint table, as in eval_kernel
             const int rows = C > Cy ? C : Cy;
             for (int i = lane; i < rows * 4; i += 64) {
@@ -802,7 +832,7 @@ __global__ void __launch_bounds__(256) clearance_kernel(const EvalArgs<T> a)
             P0[lane] = px; P1[lane] = py; P2[lane] = pz; YW[lane] = yw;
         }
         wave_lds_sync();
-        clearance_chunk<T, ROT, true, true>(a, boxes, boxes32, groups, ngroups, lane, k0, a.Sp, P0, P1, P2, YW, CC, SS, MINKEY, ARG, QUEUE);
+        clearance_chunk<T, ROT, true, true>(a, boxes, boxes32, groups, ngroups, n_wide, lane, k0, a.Sp, P0, P1, P2, YW, CC, SS, MINKEY, ARG, QUEUE);
         if (k < a.Sp) {
             a.pre_d[cand * a.Sp + k] = key_to_distance<T>(MINKEY[lane]);
             a.pre_arg[cand * a.Sp + k] = ARG[lane];
