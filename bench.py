@@ -212,7 +212,35 @@ def main():
         extras["colliding_fraction"] = float((fl & 1).mean())
         extras["feasible_fraction"] = float(((fl & 2) != 0).mean())
 
+    # second headline metric (BASELINE config 5, bounded): scenarios solved per second, every rank its own scenarios
+    # x 32 restarts of device-resident CEM to the reference stopping rule; not part of `value`
+    sc = {}
+    try:
+        from motion_planning_amd.batch import solve_scenarios_cem
+        from motion_planning_amd.synthetic import wall_scenario_problems
+
+        n_sc = int(os.environ.get("MP_BENCH_SCENARIOS", "512"))
+        probs = wall_scenario_problems(_native.build_basis, n_sc, seed=2 + 7919 * rank)
+        sync()
+        t1 = time.perf_counter()
+        res = solve_scenarios_cem(probs, restarts=32, device=local_rank, dtype=np.float64, population_size=64, max_iter=90,
+                                  seed=1000 * rank)
+        cnt = torch.tensor([float(res["solved"].sum()), float(n_sc)], dtype=torch.float64, device="cuda")
+        sync()
+        el5 = time.perf_counter() - t1
+        if world > 1:
+            dist.all_reduce(cnt)
+            t5 = torch.tensor([el5], dtype=torch.float64, device="cuda")
+            dist.all_reduce(t5, op=dist.ReduceOp.MAX)
+            el5 = float(t5.item())
+        sc = {"scenarios_solved_per_s": float(cnt[0].item()) / el5, "scenarios": int(cnt[1].item()), "restarts": 32,
+              "solved_fraction": float(cnt[0].item() / cnt[1].item()), "wall_s": el5,
+              "workload": "BASELINE config 5 (bounded): generated wall-building scenarios, CEM pop 64 to the reference stop rule, S=101"}
+    except Exception as exc:   # the headline line must survive a failure of the side metric
+        sc = {"error": repr(exc)}
+
     if rank == 0:
+        extras["config5"] = sc
         line = {
             "metric": "spline cost+grad evals/sec (node)",
             "value": world * N_CAND * args.steps / elapsed,
