@@ -232,6 +232,7 @@ __device__ __forceinline__ T pose_distance(const Pose<T> &pw, T ax, T ay, T az, 
 {
     T sep2 = Lim<T>::inf(), pen = Lim<T>::inf();
     int isep = -1, ipen = -1;
+    if (nb <= 0) { arg_box = -1; return Lim<T>::inf(); }   // empty scene (and nothing to prefetch)
     // The box table is read-only for the whole launch and the index is wave-uniform: read it
     // through the constant address space so the records arrive over the scalar data path
     // (s_load into SGPRs), and fetch record b+1 while record b is being worked on.
@@ -474,8 +475,12 @@ __device__ __forceinline__ T point_distance(T px, T py, T pz, const BoxRec<T> *_
 {
     T out2 = Lim<T>::inf(), in = Lim<T>::inf();
     int iout = -1, iin = -1;
+    if (nb <= 0) { arg_box = -1; return Lim<T>::inf(); }   // empty scene (and nothing to prefetch)
+    // boxes and b are wave-uniform: records come over the scalar data path, one record ahead (as in pose_distance)
+    BoxRec<T> nxt = load_box_uniform(boxes, 0);
     for (int b = 0; b < nb; ++b) {
-        const BoxRec<T> bx = boxes[b];
+        const BoxRec<T> bx = nxt;
+        nxt = load_box_uniform(boxes, b + 1 < nb ? b + 1 : b);
         T ex = px - bx.cx, ey = py - bx.cy;
         if (rot) {
             const T exw = ex, eyw = ey;
