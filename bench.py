@@ -68,10 +68,20 @@ def cpu_baseline(problem, X, budget_s=8.0):
         while time.perf_counter() - t0 < budget_s:
             total += sum(pool.map(run, starts[:4 * cores]))
     el = time.perf_counter() - t0
+    # reference-shaped path (SciPy spline per call, NumPy terms, per-sample distance loop; one core like the reference)
+    from oracle import numpy_path
+
+    m, t0 = 0, time.perf_counter()
+    while time.perf_counter() - t0 < 2.0:
+        numpy_path.objective_batch(problem, X[m:m + 16])
+        m += 16
+    shaped = m / (time.perf_counter() - t0)
     return {"value": total / el, "unit": "evals/s", "cores": cores, "kind": "port", "value_one_core": one,
+            "reference_shaped_numpy_one_core": shaped,
             "sample": f"{total} candidates of the same batch (64 samples x 50 boxes, fp64, cost+grad) in {el:.1f} s of "
                       f"oracle/mp_oracle.c on {cores} threads; {done} candidates in {budget_s:.0f} s on one core "
-                      f"({os.cpu_count()} CPUs visible)"}
+                      f"({os.cpu_count()} CPUs visible); reference-shaped NumPy/SciPy path (oracle/numpy_path.py, cost only): "
+                      f"{m} candidates in 2 s on one core"}
 
 
 def main():

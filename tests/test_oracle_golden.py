@@ -92,3 +92,22 @@ def test_window_integers_of_the_demo_config():
     case = next(c for c in CASES if c["name"] == "front_sub3")
     p = H.problem_for_case(case)
     assert p.idx_safe[-1] == 100 and p.idx_safe[-2] == 99 and p.n_safe == 35
+
+
+def test_reference_shaped_numpy_path_matches_the_reference_goldens(oracle_lib):
+    """oracle/numpy_path.py (SciPy spline per call, NumPy terms, per-sample distance loop) against the 16-tuples the
+    real reference returned (G3), and against the C oracle's clearance profile."""
+    from oracle import numpy_path as npth
+    from tests import helpers as H
+
+    g3 = H.load_g3()
+    for case in H.load_cases():
+        prob = H.problem_for_case(case)
+        name = case["name"]
+        X, gold = g3[f"{name}__X"], g3[f"{name}__out"]
+        ref = oracle_lib.evaluate(prob, X)
+        for i in range(0, X.shape[0], 3):
+            cost, terms, d = npth.objective_single(prob, X[i])
+            assert cost == pytest.approx(gold[i, 0], rel=1e-10, abs=1e-12), (name, i)
+            np.testing.assert_allclose(terms, gold[i, 1:], rtol=1e-9, atol=1e-12, err_msg=f"{name}[{i}]")
+            np.testing.assert_allclose(d, ref["dist"][i], rtol=1e-12, atol=1e-13, err_msg=f"{name}[{i}] clearance")
