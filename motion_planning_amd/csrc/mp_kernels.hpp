@@ -176,6 +176,14 @@ __device__ __forceinline__ void clearance_chunk(const EvalArgs<T> &a, const BoxR
             Pose<T> ps;
             pose_setup(ps, qx, qy, P2[ss], qc, qs, a.ax, a.ay);
             key = pair_key(ps, a.ax, a.ay, a.az, bcx, bcy, bx.cz, bx.hx, bx.hy, bx.hz);
+#ifdef MP_STATS
+            {   // how many evaluated pairs needed the rectangle distance (xy-separated), how many were overlaps
+                PairOut<T> po;
+                pair_axes(ps, a.ax, a.ay, a.az, bcx, bcy, bx.cz, bx.hx, bx.hy, bx.hz, po);
+                if (po.gsat > T(0)) atomicAdd(&g_stats[5], 1ull);
+                if (!(po.gsat > T(0)) && !(po.gz > T(0))) atomicAdd(&g_stats[6], 1ull);
+            }
+#endif
             oldk = MINKEY[kk];
         }
         wave_lds_sync();
