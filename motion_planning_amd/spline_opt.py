@@ -163,12 +163,51 @@ _HYBRID_CEM_DEFAULTS = dict(population_size=48, elite_frac=0.2, max_iter=60, tol
 _HYBRID_POWELL_DEFAULTS = dict(maxiter=80, xtol=1e-3, ftol=1e-3)
 
 
+_GRAD_DEFAULTS = dict(iters=40, restarts=16, jitter=0.05, step0=0.05, shrink=0.5, grow=1.3)
+
+
+def _refine_with_gradient(value_and_grad: Callable, x: np.ndarray, sigma0: np.ndarray, iters: int = 40, restarts: int = 16,
+                          jitter: float = 0.05, step0: float = 0.05, shrink: float = 0.5, grow: float = 1.3,
+                          seed: Optional[int] = None) -> Dict:
+    """Batched local refinement with the analytic (sub)gradient — the stand-in for the reference's derivative-free
+    Powell stage (ref :338-359) that a batched evaluator makes cheap: ``restarts`` copies of ``x`` (the first exact,
+    the others jittered by ``jitter * sigma0``) descend together, one evaluator call per iteration.
+
+    Per copy: a step of its own length along the gradient normalised in sigma0 units (metres and degrees mix in x),
+    accepted only if the cost drops, otherwise the step shrinks — monotone descent that tolerates the kinks of the
+    sub-gradient.  ``value_and_grad(X) -> (cost (n,), grad (n, D))``."""
+    rng = np.random.default_rng(seed)
+    x = np.asarray(x, dtype=float)
+    scale = np.asarray(sigma0, dtype=float)
+    X = np.repeat(x[None, :], max(1, int(restarts)), axis=0)
+    X[1:] += jitter * scale[None, :] * rng.normal(size=X[1:].shape)
+    cost, grad = value_and_grad(X)
+    cost, grad = np.array(cost, dtype=float), np.array(grad, dtype=float)
+    step = np.full(X.shape[0], float(step0))
+    n_eval = X.shape[0]
+    for _ in range(int(iters)):
+        gs = grad * scale[None, :]
+        gnorm = np.maximum(np.linalg.norm(gs, axis=1, keepdims=True), 1e-30)
+        trial = X - step[:, None] * scale[None, :] * gs / gnorm
+        c2, g2 = value_and_grad(trial)
+        n_eval += X.shape[0]
+        better = np.asarray(c2) < cost
+        X = np.where(better[:, None], trial, X)
+        grad = np.where(better[:, None], g2, grad)
+        cost = np.where(better, c2, cost)
+        step = np.where(better, step * grow, step * shrink)
+    i = int(np.argmin(cost))
+    return {"x": X[i].copy(), "fun": float(cost[i]), "nit": int(iters), "n_eval": int(n_eval)}
+
+
 def _solve_optimizer(objective_single, x0, sigma0, method: str, options: Optional[Dict] = None,
-                     objective_batch: Optional[Callable] = None) -> Dict:
+                     objective_batch: Optional[Callable] = None, value_and_grad: Optional[Callable] = None) -> Dict:
     """Method dispatch and option merging of the reference (ref :280-388).
 
     ``objective_single(x)`` returns a tuple whose element 0 is the cost; ``objective_batch(X)``
-    (optional) returns the cost vector of a population in one call."""
+    (optional) returns the cost vector of a population in one call.  One method beyond the reference's:
+    ``"CEM-GRAD"`` — the hybrid with the Powell stage replaced by ``_refine_with_gradient`` (needs
+    ``value_and_grad``; options ``{"cem": {...}, "grad": {...}}``)."""
     if objective_batch is None:
         def objective_batch(X):
             return np.array([objective_single(x)[0] for x in X], dtype=float)
@@ -184,6 +223,28 @@ def _solve_optimizer(objective_single, x0, sigma0, method: str, options: Optiona
         res = _cem_optimize(objective_batch, x0=x0, sigma0=sigma0, **cem)
         return {"x": res["x"], "success": bool(res["success"]), "message": str(res["message"]), "nit": int(res["nit"]),
                 "fun": float(res["fun"])}
+
+    if name == "CEM-GRAD":
+        if value_and_grad is None:
+            raise ValueError("method 'CEM-GRAD' needs an evaluator with gradients")
+        cem, grad_opt = dict(_HYBRID_CEM_DEFAULTS), dict(_GRAD_DEFAULTS)
+        if options:
+            if isinstance(options.get("cem"), dict):
+                cem.update(options["cem"])
+            if isinstance(options.get("grad"), dict):
+                grad_opt.update(options["grad"])
+            for key, val in options.items():
+                if key in cem:
+                    cem[key] = val
+                if key in grad_opt:
+                    grad_opt[key] = val
+        stage1 = _cem_optimize(objective_batch, x0=x0, sigma0=sigma0, **cem)
+        stage2 = _refine_with_gradient(value_and_grad, stage1["x"], sigma0, seed=cem.get("seed"), **grad_opt)
+        if stage2["fun"] <= float(stage1["fun"]):
+            return {"x": stage2["x"], "success": True, "message": "Hybrid CEM+gradient: refined", "fun": stage2["fun"],
+                    "nit": int(stage1["nit"]) + int(stage2["nit"])}
+        return {"x": stage1["x"], "success": bool(stage1["success"]), "message": "Hybrid CEM+gradient: kept CEM result",
+                "nit": int(stage1["nit"]), "fun": float(stage1["fun"])}
 
     if name in {"CEM-POWELL", "HYBRID"}:
         cem, powell = dict(_HYBRID_CEM_DEFAULTS), dict(_HYBRID_POWELL_DEFAULTS)
@@ -315,8 +376,12 @@ def optimize_bspline_path(
     def objective_batch(X):
         return np.asarray(evaluate(X)["cost"], dtype=float)
 
+    def value_and_grad(X):
+        out = evaluate(X, want_grad=True)
+        return np.asarray(out["cost"], dtype=float), np.asarray(out["grad"], dtype=float)
+
     opt = _solve_optimizer(objective_single, x0=problem.x0, sigma0=problem.sigma0, method=method, options=options,
-                           objective_batch=objective_batch)
+                           objective_batch=objective_batch, value_and_grad=value_and_grad)
     x_opt = np.asarray(opt["x"], dtype=float)
     vias_opt = x_opt[:n_pos].reshape(problem.n_free, 3)
     if problem.n_yaw_free > 0:
@@ -425,8 +490,12 @@ def optimize_bspline_with_vias(
     def objective_batch(X):
         return np.asarray(evaluate(X)["cost"], dtype=float)
 
+    def value_and_grad(X):
+        out = evaluate(X, want_grad=True)
+        return np.asarray(out["cost"], dtype=float), np.asarray(out["grad"], dtype=float)
+
     opt = _solve_optimizer(objective_single, x0=problem.x0, sigma0=problem.sigma0, method=method, options=options,
-                           objective_batch=objective_batch)
+                           objective_batch=objective_batch, value_and_grad=value_and_grad)
     x_opt = np.asarray(opt["x"], dtype=float)
     vias_opt = x_opt.reshape(n_additional_vias, 3)
     S_opt = build_cubic_bspline(np.vstack([start, via, vias_opt, goal]))

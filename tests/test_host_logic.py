@@ -161,3 +161,30 @@ def test_static_block_rotations():
         scene_to_boxes(BoxList([Block((1, 1, 1), (0, 0, 0), quat=(0.3826834323650898, 0.0, 0.0, 0.9238795325112867))]))
     with pytest.raises(ValueError):
         scene_to_boxes(BoxList([Block((1, 1, 1), (0, 0, 0), quat=(0.0, 0.0, 0.5, 0.5))]))
+
+
+def test_cem_grad_hybrid_extension(oracle_lib):
+    """'CEM-GRAD' (not in the reference): CEM, then batched gradient refinement; never worse than its own CEM stage,
+    deterministic for a seed, and refused without a gradient-capable evaluator."""
+    from motion_planning_amd import spline_opt as so
+    from motion_planning_amd.configs import BASE_CONFIG
+    from oracle.oracle import OracleEvaluator
+
+    sc = H.load_scenarios()["step_02_second_in_front"]
+    kw = {k: v for k, v in BASE_CONFIG.items() if k not in ("method", "options")}
+    args = (BoxList(H.blocks_from(sc["blocks"])), sc["start"], sc["goal"])
+    common = dict(moving_block_size=tuple(sc["moving_block_size"]), start_yaw_deg=sc["start_yaw_deg"], goal_yaw_deg=sc["goal_yaw_deg"],
+                  goal_approach_normals=np.asarray(sc["goal_normals"], float), evaluator_factory=OracleEvaluator, **kw)
+    opts = {"seed": 3, "cem": {"max_iter": 25}, "grad": {"iters": 15, "restarts": 8}}
+    _, v1, i1 = so.optimize_bspline_path(*args, method="CEM-GRAD", options=opts, **common)
+    _, v2, i2 = so.optimize_bspline_path(*args, method="cem-grad", options=opts, **common)
+    _, _, i0 = so.optimize_bspline_path(*args, method="CEM", options={"seed": 3, "population_size": 48, "max_iter": 25}, **common)
+    np.testing.assert_array_equal(v1, v2)
+    assert i1["fun"] == i2["fun"] and i1["fun"] <= i0["fun"] + 1e-12
+    assert i1["message"].startswith("Hybrid CEM+gradient")
+    with pytest.raises(ValueError, match="CEM-GRAD"):
+        so._solve_optimizer(lambda x: (float(np.sum(x * x)),), np.ones(3), np.ones(3), "CEM-GRAD")
+    # the refinement alone on a smooth bowl: converges to the minimum
+    res = so._refine_with_gradient(lambda X: (np.sum((X - 2.0) ** 2, axis=1), 2.0 * (X - 2.0)), np.zeros(4), np.ones(4), iters=80,
+                                   restarts=4, step0=0.5, seed=0)
+    assert res["fun"] < 1e-3
