@@ -28,7 +28,9 @@ extern "C" {
 
 /* ---- limits ------------------------------------------------------------------ */
 #define MP_MAX_CTRL 16    /* waypoints per spline (start + vias + goal)            */
-#define MP_MAX_SAMPLES 1024 /* n_samples_curve                                      */
+#define MP_MAX_SAMPLES 1024 /* n_samples_curve (gradient launches: the per-wave LDS slice
+                               must fit 160 KB, i.e. <= ~860 fp64 / ~1024 fp32 samples;
+                               larger ones return MP_E_UNSUPPORTED)              */
 #define MP_NTERMS 15      /* cost terms, order of the weighted sum spline_opt.py:605-621 */
 
 /* ---- error codes ------------------------------------------------------------- */

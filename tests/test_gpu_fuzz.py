@@ -94,3 +94,42 @@ def test_random_vias_configuration_matches_oracle(seed, oracle_lib):
     ref = oracle_lib.evaluate(prob, X)
     _compare(out, ref, np.float64)
     ctx.close()
+
+
+@pytest.mark.parametrize("S", [256, 400, abi.MP_MAX_SAMPLES])
+def test_maximum_sizes(S, oracle_lib):
+    """Largest supported trajectories: 16 waypoints, up to MP_MAX_SAMPLES samples (an LDS slice beyond 64 KB per wave in
+    the fused gradient kernel), fused and split clearance."""
+    import os
+
+    from motion_planning_amd import _native as native
+
+    rng = np.random.default_rng(S)
+    start, goal = np.array([-1.5, -1.5, 1.5]), np.array([1.5, 1.5, 0.4])
+    scene = random_scene(40, 11, (0.1, 0.5), start, goal)
+    prob = build_path_problem(scene, start, goal, native.build_basis, n_vias=14, n_samples_curve=S, moving_block_size=(0.9, 0.6, 0.6),
+                              start_yaw_deg=0.0, goal_yaw_deg=90.0, n_yaw_vias=14, w_curv=0.1, w_safe=50.0, w_safe_preferred=5.0,
+                              preferred_safety_margin=0.05, w_yaw_monotonic=1.0, w_approach_rebound=1.0)
+    assert prob.n_ctrl == abi.MP_MAX_CTRL
+    X = prob.x0 + 0.3 * prob.sigma0 * rng.normal(size=(9, prob.dim))
+    ref = oracle_lib.evaluate(prob, X)
+    for force in ("0", "1"):
+        os.environ["MP_SPLIT_CLEARANCE"] = force
+        try:
+            ctx = native.Context(0)
+            ctx.set_problem(prob)
+            if S <= 800:
+                out = ctx.eval(X, want_grad=True, want_dist=True)
+                _compare(out, ref, np.float64)
+            else:
+                # a gradient launch keeps 22 arrays of S elements per wave in LDS: beyond ~860 samples (fp64) that
+                # exceeds the CU's 160 KB and is refused loudly; the cost-only launch (10 arrays) still fits
+                with pytest.raises(native.NativeError, match="LDS per wave"):
+                    ctx.eval(X, want_grad=True)
+                out = ctx.eval(X, want_grad=False, want_terms=True, want_dist=True)
+                np.testing.assert_array_equal(out["dist"], ref["dist"])
+                np.testing.assert_array_equal(out["flags"], ref["flags"])
+                assert H.rel_err(out["cost"], ref["cost"]).max() < 1e-9
+            ctx.close()
+        finally:
+            os.environ.pop("MP_SPLIT_CLEARANCE", None)
