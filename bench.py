@@ -126,7 +126,9 @@ def main():
     Xh = synthetic_candidates(problem, N_CAND, seed=100 + rank, dtype=np_dtype)   # this rank's index shard
     X = torch.from_numpy(Xh).cuda()
     db = DeviceBatch(problem, N_CAND, device=local_rank, dtype=np_dtype, want_grad=True)
-    gather_buf = [torch.empty(world * N_CAND, 3, dtype=tdtype, device="cuda") for _ in range(2)] if world > 1 else None
+    # collectives run on device tensors over RCCL; the gloo rehearsal (one-GPU box) stages them through the host
+    coll_dev = "cuda" if backend == "nccl" else "cpu"
+    gather_buf = [torch.empty(world * N_CAND, 3, dtype=tdtype, device=coll_dev) for _ in range(2)] if world > 1 else None
     packed_buf = [torch.empty(N_CAND, 3, dtype=tdtype, device="cuda") for _ in range(2)] if world > 1 else None
 
     def step(i, pending):
@@ -139,7 +141,8 @@ def main():
             pk[:, 0].copy_(out["cost"])
             pk[:, 1].copy_(out["min_clear"])
             pk[:, 2].copy_(out["flags"])
-            pending.append(dist.all_gather_into_tensor(gather_buf[i % 2], pk, async_op=True))
+            src = pk if coll_dev == "cuda" else pk.cpu()
+            pending.append(dist.all_gather_into_tensor(gather_buf[i % 2], src, async_op=True))
         return out
 
     def sync():
@@ -163,7 +166,7 @@ def main():
     sync()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -235,12 +238,12 @@ def main():
         t1 = time.perf_counter()
         res = solve_scenarios_cem(probs, restarts=32, device=local_rank, dtype=np.float64, population_size=64, max_iter=90,
                                   seed=1000 * rank)
-        cnt = torch.tensor([float(res["solved"].sum()), float(n_sc)], dtype=torch.float64, device="cuda")
+        cnt = torch.tensor([float(res["solved"].sum()), float(n_sc)], dtype=torch.float64, device=coll_dev)
         sync()
         el5 = time.perf_counter() - t1
         if world > 1:
             dist.all_reduce(cnt)
-            t5 = torch.tensor([el5], dtype=torch.float64, device="cuda")
+            t5 = torch.tensor([el5], dtype=torch.float64, device=coll_dev)
             dist.all_reduce(t5, op=dist.ReduceOp.MAX)
             el5 = float(t5.item())
         sc = {"scenarios_solved_per_s": float(cnt[0].item()) / el5, "scenarios": int(cnt[1].item()), "restarts": 32,
