@@ -165,12 +165,14 @@ int mp_timer_stop(mp_ctx *ctx, float *elapsed_ms); /* synchronises on the stop e
 
 /* ---- scene: replaces Scene.blocks / Block (geom/scene.py:10-45, geom/blocks.py:8-21)
  * SoA host arrays of box centres and HALF extents.  quat_xyzw may be NULL (all
- * identity).  A static box may be rotated about z (x = y = 0 in its quaternion,
- * Block.quat of geom/blocks.py:8-21): its (cos, sin) are taken as R00 = 1 - 2zz,
- * R10 = 2wz like the reference's quat_to_rot (geom/utils.py:3-14) and every pair is
- * evaluated in the box's own frame.  A box tilted about x or y returns
- * MP_E_UNSUPPORTED (no shipped scenario has one); a quaternion
- * that is not of unit length returns MP_E_ARG.
+ * identity); otherwise unit quaternions [x,y,z,w] (Block.quat, geom/blocks.py:8-21),
+ * turned into rotations like the reference's quat_to_rot (geom/utils.py:3-14):
+ *  - x = y = 0 (rotation about z): (cos, sin) = (1 - 2zz, 2wz); the pair is
+ *    evaluated in the box's own frame with the axis-aligned formulas;
+ *  - anything else (tilted box): the full matrix; the pair goes through the general
+ *    OBB routine (15-axis SAT depth / closest vertex-face and edge-edge features),
+ *    exact but ~30x the work of a z-aligned pair.
+ * A quaternion that is not of unit length (1e-9) returns MP_E_ARG.
  * n_boxes == 0 is legal: distances are +inf (scene.py:112-113).  Replacing the scene
  * invalidates the current problem: call mp_set_problem again before mp_eval. */
 int mp_set_scene(mp_ctx *ctx, int32_t n_boxes, const double *cx, const double *cy,

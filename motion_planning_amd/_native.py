@@ -13,7 +13,7 @@ from typing import Optional, Sequence
 import numpy as np
 
 from . import _abi as abi
-from .problem import PathProblem, as_boxes8
+from .problem import PathProblem, as_boxes10
 
 import os
 
@@ -145,14 +145,13 @@ class Context:
 
     # -- scene / problem --
     def set_scene(self, boxes: np.ndarray) -> None:
-        """(B,6) rows cx,cy,cz,hx,hy,hz, or (B,8) with the (z, w) of each box's yaw-only quaternion appended."""
-        b = as_boxes8(boxes)
+        """(B,6) rows cx,cy,cz,hx,hy,hz; (B,8) with the (z, w) of each box's yaw-only quaternion appended; or (B,10)
+        with the full quaternion (x, y, z, w) of each box."""
+        b = as_boxes10(boxes)
         cols = [np.ascontiguousarray(b[:, i]) for i in range(6)]
         quat = None
-        if b.shape[0] and not (np.all(b[:, 6] == 0.0) and np.all(b[:, 7] == 1.0)):
-            quat = np.zeros((b.shape[0], 4), dtype=np.float64)
-            quat[:, 2] = b[:, 6]
-            quat[:, 3] = b[:, 7]
+        if b.shape[0] and not (np.all(b[:, 6:9] == 0.0) and np.all(b[:, 9] == 1.0)):
+            quat = np.ascontiguousarray(b[:, 6:10])
         self._check(self.lib.mp_set_scene(self._h, b.shape[0], *[_p(c) for c in cols], _p(quat)))
         self.n_boxes = int(b.shape[0])
 
@@ -162,7 +161,7 @@ class Context:
             problems = [problems]
         p0 = problems[0]
         if upload_scene:
-            self.set_scene(np.vstack([as_boxes8(p.boxes) for p in problems]))
+            self.set_scene(np.vstack([as_boxes10(p.boxes) for p in problems]))
         cfg = p0.config_struct()
         tasks = (abi.MpTask * len(problems))()
         off = 0

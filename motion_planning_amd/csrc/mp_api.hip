@@ -40,7 +40,8 @@ struct mp_ctx {
     DevBuf boxes, boxes32, groups;
     std::vector<double> h_boxes;  // host copy of the scene (n x 6) for the per-task bound tables
     float scene_radius = 0.f;
-    int has_rot = 0;              // any static box with a yaw of its own
+    int has_rot = 0;              // 0 axis-aligned scene, 1 some boxes have a yaw of their own, 2 some are tilted
+    DevBuf tilt;                  // rotation matrices (9 values each, context dtype) of the tilted boxes
     int n_boxes = 0;
     bool have_scene = false;
 
@@ -206,36 +207,51 @@ template <typename T> void to_vec(const double *src, size_t n, std::vector<T> &o
     for (size_t i = 0; i < n; ++i) out[i] = (T)src[i];
 }
 
+// cb/sb: cos / sin of each box's own yaw (1, 0 = axis aligned); sb = 2 marks a tilted box whose cb is the index of its
+// rotation matrix (world <- box, row major) in rtab
 template <typename T> int upload_scene(mp_ctx *ctx, int n, const double *cx, const double *cy, const double *cz,
                                         const double *hx, const double *hy, const double *hz, const double *cb,
-                                        const double *sb)
+                                        const double *sb, const std::vector<double> &rtab)
 {
     std::vector<mp::BoxRec<T>> rec((size_t)std::max(n, 1));
-    bool any_rot = false;
+    int rot = 0;
     for (int i = 0; i < n; ++i) {
         rec[i].cx = (T)cx[i]; rec[i].cy = (T)cy[i]; rec[i].cz = (T)cz[i];
         rec[i].hx = (T)hx[i]; rec[i].hy = (T)hy[i]; rec[i].hz = (T)hz[i];
         rec[i].cb = (T)cb[i]; rec[i].sb = (T)sb[i];
-        any_rot = any_rot || !(cb[i] == 1.0 && sb[i] == 0.0);
+        if (sb[i] == 2.0) rot = 2;
+        else if (!(cb[i] == 1.0 && sb[i] == 0.0)) rot = std::max(rot, 1);
     }
     int rc = upload(ctx, ctx->boxes, rec.data(), (size_t)n * sizeof(mp::BoxRec<T>));
     if (rc) return rc;
-    ctx->has_rot = any_rot ? 1 : 0;
+    std::vector<T> rt;
+    to_vec<T>(rtab.data(), rtab.size(), rt);
+    if (rt.empty()) rt.assign(9, T(0));
+    if ((rc = upload(ctx, ctx->tilt, rt.data(), rt.size() * sizeof(T)))) return rc;
+    ctx->has_rot = rot;
     // host copy (centre + half extents of each box's WORLD AABB) + scene radius (scales the slack of the fp32
-    // bound pass); the fp32 tables are built per task.  The AABB of a yaw-rotated box bounds the box, so the
+    // bound pass); the fp32 tables are built per task.  The AABB of a rotated box bounds the box, so the
     // bound pass stays a valid lower bound of the distance.
     ctx->h_boxes.resize((size_t)n * 6);
     double radius = 0.0;
     for (int i = 0; i < n; ++i) {
         double *r = &ctx->h_boxes[(size_t)i * 6];
-        const double ac = std::fabs(cb[i]), as = std::fabs(sb[i]);
-        const double hxw = (cb[i] == 1.0 && sb[i] == 0.0) ? hx[i] : (ac * hx[i] + as * hy[i]) * (1.0 + 1e-12);
-        const double hyw = (cb[i] == 1.0 && sb[i] == 0.0) ? hy[i] : (as * hx[i] + ac * hy[i]) * (1.0 + 1e-12);
-        r[0] = cx[i]; r[1] = cy[i]; r[2] = cz[i]; r[3] = hxw; r[4] = hyw; r[5] = hz[i];
-        radius = std::max({radius, std::fabs(cx[i]) + hxw, std::fabs(cy[i]) + hyw, std::fabs(cz[i]) + hz[i]});
+        double hxw = hx[i], hyw = hy[i], hzw = hz[i];
+        if (sb[i] == 2.0) {
+            const double *R = &rtab[(size_t)9 * (size_t)cb[i]];
+            hxw = (std::fabs(R[0]) * hx[i] + std::fabs(R[1]) * hy[i] + std::fabs(R[2]) * hz[i]) * (1.0 + 1e-12);
+            hyw = (std::fabs(R[3]) * hx[i] + std::fabs(R[4]) * hy[i] + std::fabs(R[5]) * hz[i]) * (1.0 + 1e-12);
+            hzw = (std::fabs(R[6]) * hx[i] + std::fabs(R[7]) * hy[i] + std::fabs(R[8]) * hz[i]) * (1.0 + 1e-12);
+        } else if (!(cb[i] == 1.0 && sb[i] == 0.0)) {
+            const double ac = std::fabs(cb[i]), as = std::fabs(sb[i]);
+            hxw = (ac * hx[i] + as * hy[i]) * (1.0 + 1e-12);
+            hyw = (as * hx[i] + ac * hy[i]) * (1.0 + 1e-12);
+        }
+        r[0] = cx[i]; r[1] = cy[i]; r[2] = cz[i]; r[3] = hxw; r[4] = hyw; r[5] = hzw;
+        radius = std::max({radius, std::fabs(cx[i]) + hxw, std::fabs(cy[i]) + hyw, std::fabs(cz[i]) + hzw});
     }
     ctx->scene_radius = (float)radius;
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));  // rec is a local
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));  // rec and rt are locals
     return MP_OK;
 }
 
@@ -377,7 +393,7 @@ template <typename T> int upload_problem(mp_ctx *ctx, const mp_task *tasks)
     return MP_OK;
 }
 
-template <typename T, int MODEL, bool GRAD, bool ROT, bool PRE>
+template <typename T, int MODEL, bool GRAD, int ROT, bool PRE>
 int launch_eval_p(mp_ctx *ctx, const mp::EvalArgs<T> &args, int wpb, int blocks, size_t lds_bytes)
 {
     auto kern = mp::eval_kernel<T, MODEL, GRAD, ROT, PRE>;
@@ -389,7 +405,7 @@ int launch_eval_p(mp_ctx *ctx, const mp::EvalArgs<T> &args, int wpb, int blocks,
     return MP_OK;
 }
 
-template <typename T, int MODEL, bool GRAD, bool ROT>
+template <typename T, int MODEL, bool GRAD, int ROT>
 int launch_eval_r(mp_ctx *ctx, const mp::EvalArgs<T> &args, int wpb, int blocks, size_t lds_bytes)
 {
     if (MODEL == 1 && args.pre_d) return launch_eval_p<T, MODEL, GRAD, ROT, MODEL == 1>(ctx, args, wpb, blocks, lds_bytes);
@@ -399,8 +415,9 @@ int launch_eval_r(mp_ctx *ctx, const mp::EvalArgs<T> &args, int wpb, int blocks,
 template <typename T, int MODEL, bool GRAD>
 int launch_eval_k(mp_ctx *ctx, const mp::EvalArgs<T> &args, int wpb, int blocks, size_t lds_bytes)
 {
-    return ctx->has_rot ? launch_eval_r<T, MODEL, GRAD, true>(ctx, args, wpb, blocks, lds_bytes)
-                        : launch_eval_r<T, MODEL, GRAD, false>(ctx, args, wpb, blocks, lds_bytes);
+    if (ctx->has_rot == 2) return launch_eval_r<T, MODEL, GRAD, 2>(ctx, args, wpb, blocks, lds_bytes);
+    return ctx->has_rot ? launch_eval_r<T, MODEL, GRAD, 1>(ctx, args, wpb, blocks, lds_bytes)
+                        : launch_eval_r<T, MODEL, GRAD, 0>(ctx, args, wpb, blocks, lds_bytes);
 }
 
 template <typename T>
@@ -425,6 +442,7 @@ int launch_eval(mp_ctx *ctx, long long n, const void *X, const int32_t *task_of,
     a.tasks = (const mp::DevTask<T> *)ctx->d_tasks.p; a.boxes = (const mp::BoxRec<T> *)ctx->boxes.p;
     a.boxes32 = (const mp::BoxRec32 *)ctx->boxes32.p; a.groups = (const mp::BoxRec32 *)ctx->groups.p;
     a.scene_radius = ctx->scene_radius;
+    a.tilt = (const T *)ctx->tilt.p;
     a.X = (const T *)X; a.task_of = task_of; a.cpt = ctx->cands_per_task; a.n = n;
     a.group_size = group_size; a.group_task = group_task; a.group_done = group_done;
     a.cost = (T *)cost; a.terms = (T *)terms; a.grad = (T *)grad; a.minc = (T *)minc; a.dist = (T *)dist;
@@ -467,10 +485,12 @@ int launch_eval(mp_ctx *ctx, long long n, const void *X, const int32_t *task_of,
             const long long units = n * ((c.n_safe + 63) / 64);
             const int cblocks = (int)std::min<long long>((units + 3) / 4, (long long)ctx->num_cu * 32);
             const size_t clds = (size_t)4 * mp::clearance_lds_bytes_per_wave((int)sizeof(T));
-            if (ctx->has_rot)
-                hipLaunchKernelGGL((mp::clearance_kernel<T, true>), dim3(cblocks), dim3(256), clds, ctx->stream, a);
+            if (ctx->has_rot == 2)
+                hipLaunchKernelGGL((mp::clearance_kernel<T, 2>), dim3(cblocks), dim3(256), clds, ctx->stream, a);
+            else if (ctx->has_rot)
+                hipLaunchKernelGGL((mp::clearance_kernel<T, 1>), dim3(cblocks), dim3(256), clds, ctx->stream, a);
             else
-                hipLaunchKernelGGL((mp::clearance_kernel<T, false>), dim3(cblocks), dim3(256), clds, ctx->stream, a);
+                hipLaunchKernelGGL((mp::clearance_kernel<T, 0>), dim3(cblocks), dim3(256), clds, ctx->stream, a);
             HIP_TRY(ctx, hipGetLastError());
         }
     }
@@ -603,7 +623,7 @@ int mp_destroy(mp_ctx *ctx)
     hipStreamSynchronize(ctx->stream);
     DevBuf *bufs[] = {&ctx->boxes, &ctx->boxes32, &ctx->groups, &ctx->d_idx, &ctx->d_mask, &ctx->d_M, &ctx->d_My, &ctx->d_tsched, &ctx->d_tasks,
                       &ctx->s_X, &ctx->s_taskof, &ctx->s_cost, &ctx->s_terms, &ctx->s_grad, &ctx->s_minc,
-                      &ctx->s_flags, &ctx->s_dist, &ctx->s_aux0, &ctx->s_aux1, &ctx->s_pre_d, &ctx->s_pre_arg, &ctx->c_X, &ctx->c_vals, &ctx->c_minc,
+                      &ctx->s_flags, &ctx->s_dist, &ctx->s_aux0, &ctx->s_aux1, &ctx->s_pre_d, &ctx->s_pre_arg, &ctx->tilt, &ctx->c_X, &ctx->c_vals, &ctx->c_minc,
                       &ctx->c_flags, &ctx->c_mu, &ctx->c_sigma, &ctx->c_bestx, &ctx->c_bestval, &ctx->c_prev, &ctx->c_bminc,
                       &ctx->c_bflags, &ctx->c_done, &ctx->c_nit, &ctx->c_active, &ctx->c_task, &ctx->c_x0, &ctx->c_s0,
                       &ctx->c_noise};
@@ -672,26 +692,35 @@ int mp_set_scene(mp_ctx *ctx, int32_t n_boxes, const double *cx, const double *c
     if (rc) return rc;
     if (n_boxes < 0) return fail(ctx, MP_E_ARG, "mp_set_scene: n_boxes < 0");
     if (n_boxes > 0 && (!cx || !cy || !cz || !hx || !hy || !hz)) return fail(ctx, MP_E_ARG, "mp_set_scene: NULL array");
-    std::vector<double> cb((size_t)std::max(n_boxes, 1), 1.0), sb((size_t)std::max(n_boxes, 1), 0.0);
+    std::vector<double> cb((size_t)std::max(n_boxes, 1), 1.0), sb((size_t)std::max(n_boxes, 1), 0.0), rtab;
     for (int i = 0; i < n_boxes; ++i) {
         if (!(hx[i] >= 0.0 && hy[i] >= 0.0 && hz[i] >= 0.0))
             return fail(ctx, MP_E_ARG, "mp_set_scene: box %d has a negative or NaN half extent", i);
         if (quat_xyzw) {
             const double *q = quat_xyzw + 4 * (size_t)i;
-            if (!(q[0] == 0.0 && q[1] == 0.0))
-                return fail(ctx, MP_E_UNSUPPORTED, "mp_set_scene: box %d is tilted; static boxes may only be rotated about z", i);
-            const double nn = q[2] * q[2] + q[3] * q[3];
+            const double x = q[0], y = q[1], z = q[2], w = q[3];
+            const double nn = x * x + y * y + z * z + w * w;
             if (!(std::fabs(nn - 1.0) <= 1e-9))
                 return fail(ctx, MP_E_ARG, "mp_set_scene: box %d has a quaternion that is not of unit length", i);
-            // R00 / R10 of the reference's quat_to_rot (geom/utils.py:3-14) for a pure-yaw quaternion
-            if (!(q[2] == 0.0)) {
-                cb[i] = 1.0 - 2.0 * (q[2] * q[2]);
-                sb[i] = 2.0 * (q[3] * q[2]);
+            if (x == 0.0 && y == 0.0) {
+                // R00 / R10 of the reference's quat_to_rot (geom/utils.py:3-14) for a pure-yaw quaternion
+                if (!(z == 0.0)) {
+                    cb[i] = 1.0 - 2.0 * (z * z);
+                    sb[i] = 2.0 * (w * z);
+                }
+            } else {
+                // general rotation: the full matrix of quat_to_rot, row major
+                const double xx = x * x, yy = y * y, zz = z * z, xy = x * y, xz = x * z, yz = y * z, wx = w * x, wy = w * y, wz = w * z;
+                const double R[9] = {1 - 2 * (yy + zz), 2 * (xy - wz), 2 * (xz + wy), 2 * (xy + wz), 1 - 2 * (xx + zz), 2 * (yz - wx),
+                                     2 * (xz - wy), 2 * (yz + wx), 1 - 2 * (xx + yy)};
+                cb[i] = (double)(rtab.size() / 9);
+                sb[i] = 2.0;
+                rtab.insert(rtab.end(), R, R + 9);
             }
         }
     }
-    rc = ctx->dtype == MP_F64 ? upload_scene<double>(ctx, n_boxes, cx, cy, cz, hx, hy, hz, cb.data(), sb.data())
-                              : upload_scene<float>(ctx, n_boxes, cx, cy, cz, hx, hy, hz, cb.data(), sb.data());
+    rc = ctx->dtype == MP_F64 ? upload_scene<double>(ctx, n_boxes, cx, cy, cz, hx, hy, hz, cb.data(), sb.data(), rtab)
+                              : upload_scene<float>(ctx, n_boxes, cx, cy, cz, hx, hy, hz, cb.data(), sb.data(), rtab);
     if (rc) return rc;
     ctx->n_boxes = n_boxes;
     ctx->have_scene = true;
@@ -909,11 +938,11 @@ int mp_point_sdf(mp_ctx *ctx, int64_t n, const void *pts, double point_radius, i
     if (ctx->dtype == MP_F64)
         hipLaunchKernelGGL(mp::point_sdf_kernel<double>, dim3(blocks), dim3(256), 0, ctx->stream, (long long)n,
                            (const double *)d_pts, (const mp::BoxRec<double> *)ctx->boxes.p + box_begin, box_count,
-                           point_radius, ctx->has_rot, (double *)d_out);
+                           point_radius, ctx->has_rot, (const double *)ctx->tilt.p, (double *)d_out);
     else
         hipLaunchKernelGGL(mp::point_sdf_kernel<float>, dim3(blocks), dim3(256), 0, ctx->stream, (long long)n,
                            (const float *)d_pts, (const mp::BoxRec<float> *)ctx->boxes.p + box_begin, box_count,
-                           (float)point_radius, ctx->has_rot, (float *)d_out);
+                           (float)point_radius, ctx->has_rot, (const float *)ctx->tilt.p, (float *)d_out);
     HIP_TRY(ctx, hipGetLastError());
     if (mem == MP_MEM_HOST) {
         HIP_TRY(ctx, hipMemcpyAsync(out, d_out, (size_t)n * es, hipMemcpyDeviceToHost, ctx->stream));
@@ -948,12 +977,13 @@ int mp_box_sdf(mp_ctx *ctx, int64_t n, const void *pos, const void *yaw_deg, con
     if (ctx->dtype == MP_F64)
         hipLaunchKernelGGL(mp::box_sdf_kernel<double>, dim3(blocks), dim3(256), 0, ctx->stream, (long long)n,
                            (const double *)d_pos, (const double *)d_yaw,
-                           (const mp::BoxRec<double> *)ctx->boxes.p + box_begin, box_count, hx, hy, hz, (double *)d_out);
+                           (const mp::BoxRec<double> *)ctx->boxes.p + box_begin, box_count, hx, hy, hz,
+                           ctx->has_rot == 2 ? (const double *)ctx->tilt.p : nullptr, (double *)d_out);
     else
         hipLaunchKernelGGL(mp::box_sdf_kernel<float>, dim3(blocks), dim3(256), 0, ctx->stream, (long long)n,
                            (const float *)d_pos, (const float *)d_yaw,
                            (const mp::BoxRec<float> *)ctx->boxes.p + box_begin, box_count, (float)hx, (float)hy,
-                           (float)hz, (float *)d_out);
+                           (float)hz, ctx->has_rot == 2 ? (const float *)ctx->tilt.p : nullptr, (float *)d_out);
     HIP_TRY(ctx, hipGetLastError());
     if (mem == MP_MEM_HOST) {
         HIP_TRY(ctx, hipMemcpyAsync(out, d_out, (size_t)n * es, hipMemcpyDeviceToHost, ctx->stream));

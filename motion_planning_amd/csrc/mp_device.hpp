@@ -227,8 +227,12 @@ template <typename T> __device__ __forceinline__ BoxRec<T> load_box_uniform(cons
 
 // scene value for one pose: min over boxes (boxes pointer and nb are wave-uniform)
 template <typename T>
+__device__ void tilt_eval(T px, T py, T pz, T c, T s, T ax, T ay, T az, T bcx, T bcy, T bcz, T hbx, T hby, T hbz,
+                          const T *__restrict__ R, bool &separated, T &v2, T &pen);
+
+template <typename T>
 __device__ __forceinline__ T pose_distance(const Pose<T> &pw, T ax, T ay, T az, const BoxRec<T> *__restrict__ boxes,
-                                            int nb, int &arg_box)
+                                            int nb, const T *__restrict__ tilt, int &arg_box)
 {
     T sep2 = Lim<T>::inf(), pen = Lim<T>::inf();
     int isep = -1, ipen = -1;
@@ -240,6 +244,14 @@ __device__ __forceinline__ T pose_distance(const Pose<T> &pw, T ax, T ay, T az, 
     for (int b = 0; b < nb; ++b) {
         const BoxRec<T> bx = nxt;
         nxt = load_box_uniform(boxes, b + 1 < nb ? b + 1 : b);
+        if (tilt && bx.sb == T(2)) {   // general rotation
+            bool sp; T tv2, tpn;
+            tilt_eval(pw.px, pw.py, pw.pz, pw.c, pw.s, ax, ay, az, bx.cx, bx.cy, bx.cz, bx.hx, bx.hy, bx.hz, tilt + 9 * (int)bx.cb, sp, tv2, tpn);
+            const bool ts = sp && (tv2 < sep2), tp = !sp && (tpn < pen);
+            sep2 = ts ? tv2 : sep2; isep = ts ? b : isep;
+            pen = tp ? tpn : pen; ipen = tp ? b : ipen;
+            continue;
+        }
         T qx = pw.px, qy = pw.py, qc = pw.c, qs = pw.s;
         to_box_frame(bx, qx, qy, qc, qs);
         Pose<T> p;
@@ -332,6 +344,154 @@ __device__ __forceinline__ unsigned long long pair_key(const Pose<T> &p, T ax, T
     unsigned long long ks = kSepBit | Key<T>::bits(v2);
     unsigned long long kp = Key<T>::kInfBits - Key<T>::bits(mp_abs(pn));
     return separated ? ks : kp;
+}
+
+// ---- general static box (any rotation): exact distance against the yaw-rotated mover -----------------------
+// A tilted box carries sb = 2 and, in cb, the index of its rotation matrix (world <- box, row major, 9 values) in the
+// tilt table.  Overlapping: minus the smallest overlap over the 15 SAT axes; separated: the smallest of 8 + 8
+// vertex-to-box and 12 x 12 edge-to-edge squared distances, all in the box's own frame.  Same operation sequence as
+// the oracle's tilt_eval.  Deliberately not inlined: it is large, rare (no shipped scenario has a tilted block) and
+// only reachable from the ROT = 2 kernel instances.
+template <typename T> __device__ __forceinline__ bool box_is_tilted(const BoxRec<T> &bx) { return bx.sb == T(2); }
+
+template <typename T> __device__ __forceinline__ T dot3f(const T *u, const T *v) { return mp_fma(u[2], v[2], mp_fma(u[1], v[1], u[0] * v[0])); }
+
+template <typename T> __device__ __forceinline__ T point_box_d2(const T *v, const T *h)
+{
+    T q0 = mp_abs(v[0]) - h[0], q1 = mp_abs(v[1]) - h[1], q2 = mp_abs(v[2]) - h[2];
+    T m0 = q0 > T(0) ? q0 : T(0), m1 = q1 > T(0) ? q1 : T(0), m2 = q2 > T(0) ? q2 : T(0);
+    return mp_fma(m2, m2, mp_fma(m1, m1, m0 * m0));
+}
+
+template <typename T> __device__ __forceinline__ T clamp01(T v) { return v < T(0) ? T(0) : (v > T(1) ? T(1) : v); }
+
+template <typename T> __device__ __forceinline__ T seg_seg_d2(const T *P1, const T *d1, const T *P2, const T *d2)
+{
+    T r[3] = {P1[0] - P2[0], P1[1] - P2[1], P1[2] - P2[2]};
+    T a = dot3f(d1, d1), e = dot3f(d2, d2), f = dot3f(d2, r), c = dot3f(d1, r), bb = dot3f(d1, d2);
+    T denom = a * e - bb * bb;
+    T sp = T(0), tp;
+    if (denom > T(0)) sp = clamp01((bb * f - c * e) / denom);
+    T tnom = mp_fma(bb, sp, f);
+    if (tnom < T(0)) { tp = T(0); sp = clamp01(-c / a); }
+    else if (tnom > e) { tp = T(1); sp = clamp01((bb - c) / a); }
+    else tp = tnom / e;
+    T w[3];
+    for (int k = 0; k < 3; ++k) w[k] = mp_fma(-tp, d2[k], mp_fma(sp, d1[k], r[k]));
+    return dot3f(w, w);
+}
+
+// separated: v2 = squared distance; otherwise pen = largest signed SAT gap (<= 0)
+template <typename T>
+__device__ __noinline__ void tilt_eval(T px, T py, T pz, T c, T s, T ax, T ay, T az, T bcx, T bcy, T bcz, T hbx, T hby,
+                                       T hbz, const T *__restrict__ R, bool &separated, T &v2, T &pen)
+{
+    const T h[3] = {hbx, hby, hbz}, a[3] = {ax, ay, az};
+    const T dw[3] = {px - bcx, py - bcy, pz - bcz};
+    T t[3], E[3][3];
+    for (int k = 0; k < 3; ++k) {
+        t[k] = mp_fma(R[6 + k], dw[2], mp_fma(R[3 + k], dw[1], R[k] * dw[0]));
+        E[k][0] = mp_fma(R[3 + k], s, R[k] * c);
+        E[k][1] = mp_fma(R[3 + k], c, -(R[k] * s));
+        E[k][2] = R[6 + k];
+    }
+    T e[3][3];
+    for (int i = 0; i < 3; ++i)
+        for (int k = 0; k < 3; ++k) e[i][k] = E[k][i];
+    T gmax = -Lim<T>::inf();
+    for (int k = 0; k < 3; ++k) {
+        T ra = mp_fma(a[2], mp_abs(E[k][2]), mp_fma(a[1], mp_abs(E[k][1]), a[0] * mp_abs(E[k][0])));
+        T g = mp_abs(t[k]) - (h[k] + ra);
+        if (g > gmax) gmax = g;
+    }
+    for (int i = 0; i < 3; ++i) {
+        T rb = mp_fma(h[2], mp_abs(E[2][i]), mp_fma(h[1], mp_abs(E[1][i]), h[0] * mp_abs(E[0][i])));
+        T g = mp_abs(dot3f(t, e[i])) - (a[i] + rb);
+        if (g > gmax) gmax = g;
+    }
+    for (int i = 0; i < 3; ++i)
+        for (int k = 0; k < 3; ++k) {
+            const int k1 = (k + 1) % 3, k2 = (k + 2) % 3;
+            T L[3];
+            L[k] = T(0); L[k1] = -e[i][k2]; L[k2] = e[i][k1];
+            T n2 = dot3f(L, L);
+            if (!(n2 > T(1e-12))) continue;
+            T ra = mp_fma(a[2], mp_abs(dot3f(e[2], L)), mp_fma(a[1], mp_abs(dot3f(e[1], L)), a[0] * mp_abs(dot3f(e[0], L))));
+            T rb = mp_fma(h[2], mp_abs(L[2]), mp_fma(h[1], mp_abs(L[1]), h[0] * mp_abs(L[0])));
+            T g = (mp_abs(dot3f(t, L)) - (ra + rb)) / mp_sqrt(n2);
+            if (g > gmax) gmax = g;
+        }
+    if (!(gmax > T(0))) { separated = false; v2 = T(0); pen = gmax; return; }
+    T best = Lim<T>::inf();
+    for (int m = 0; m < 8; ++m) {
+        T sx = (m & 1) ? T(1) : T(-1), sy = (m & 2) ? T(1) : T(-1), sz = (m & 4) ? T(1) : T(-1);
+        T v[3];
+        for (int k = 0; k < 3; ++k) v[k] = mp_fma(sz * a[2], e[2][k], mp_fma(sy * a[1], e[1][k], mp_fma(sx * a[0], e[0][k], t[k])));
+        T d2 = point_box_d2(v, h);
+        if (d2 < best) best = d2;
+    }
+    for (int m = 0; m < 8; ++m) {
+        T u[3] = {((m & 1) ? h[0] : -h[0]) - t[0], ((m & 2) ? h[1] : -h[1]) - t[1], ((m & 4) ? h[2] : -h[2]) - t[2]};
+        T w[3] = {dot3f(u, e[0]), dot3f(u, e[1]), dot3f(u, e[2])};
+        T d2 = point_box_d2(w, a);
+        if (d2 < best) best = d2;
+    }
+    for (int i = 0; i < 3; ++i) {
+        const int i1 = (i + 1) % 3, i2 = (i + 2) % 3;
+        T d1[3] = {T(2) * a[i] * e[i][0], T(2) * a[i] * e[i][1], T(2) * a[i] * e[i][2]};
+        for (int ma = 0; ma < 4; ++ma) {
+            T s1 = (ma & 1) ? a[i1] : -a[i1], s2 = (ma & 2) ? a[i2] : -a[i2];
+            T P1[3];
+            for (int k = 0; k < 3; ++k) P1[k] = mp_fma(s2, e[i2][k], mp_fma(s1, e[i1][k], mp_fma(-a[i], e[i][k], t[k])));
+            for (int k = 0; k < 3; ++k) {
+                const int k1 = (k + 1) % 3, k2 = (k + 2) % 3;
+                T d2v[3] = {T(0), T(0), T(0)};
+                d2v[k] = T(2) * h[k];
+                for (int mb = 0; mb < 4; ++mb) {
+                    T P2[3];
+                    P2[k] = -h[k]; P2[k1] = (mb & 1) ? h[k1] : -h[k1]; P2[k2] = (mb & 2) ? h[k2] : -h[k2];
+                    T d2 = seg_seg_d2(P1, d1, P2, d2v);
+                    if (d2 < best) best = d2;
+                }
+            }
+        }
+    }
+    separated = true; v2 = best; pen = T(0);
+}
+
+template <typename T>
+__device__ __forceinline__ unsigned long long tilt_key(T px, T py, T pz, T c, T s, T ax, T ay, T az, const BoxRec<T> &bx,
+                                                       const T *__restrict__ tilt)
+{
+    bool sep; T v2, pen;
+    tilt_eval(px, py, pz, c, s, ax, ay, az, bx.cx, bx.cy, bx.cz, bx.hx, bx.hy, bx.hz, tilt + 9 * (int)bx.cb, sep, v2, pen);
+    return sep ? (kSepBit | Key<T>::bits(v2)) : (Key<T>::kInfBits - Key<T>::bits(mp_abs(pen)));
+}
+
+template <typename T>
+__device__ __forceinline__ T tilt_value(T px, T py, T pz, T c, T s, T ax, T ay, T az, const BoxRec<T> &bx, const T *__restrict__ tilt)
+{
+    bool sep; T v2, pen;
+    tilt_eval(px, py, pz, c, s, ax, ay, az, bx.cx, bx.cy, bx.cz, bx.hx, bx.hy, bx.hz, tilt + 9 * (int)bx.cb, sep, v2, pen);
+    return sep ? mp_sqrt(v2) : pen;
+}
+
+// central differences of the exact pair value in (px, py, pz, theta): the gradient of a tilted pair (see the oracle)
+template <typename T> struct TiltFd;
+template <> struct TiltFd<double> { static constexpr double h = 1e-6, ch = 0.9999999999995, sh = 9.99999999999833333e-07; };
+template <> struct TiltFd<float> { static constexpr float h = 2e-3f, ch = 0.999998000000666666578f, sh = 0.00199999866666693333f; };
+
+template <typename T>
+__device__ __forceinline__ void tilt_grad(T px, T py, T pz, T c, T s, T ax, T ay, T az, const BoxRec<T> &bx, const T *__restrict__ tilt,
+                                          T &g0, T &g1, T &g2, T &g3)
+{
+    const T hh = TiltFd<T>::h, inv2h = T(1) / (T(2) * TiltFd<T>::h);
+    g0 = (tilt_value(px + hh, py, pz, c, s, ax, ay, az, bx, tilt) - tilt_value(px - hh, py, pz, c, s, ax, ay, az, bx, tilt)) * inv2h;
+    g1 = (tilt_value(px, py + hh, pz, c, s, ax, ay, az, bx, tilt) - tilt_value(px, py - hh, pz, c, s, ax, ay, az, bx, tilt)) * inv2h;
+    g2 = (tilt_value(px, py, pz + hh, c, s, ax, ay, az, bx, tilt) - tilt_value(px, py, pz - hh, c, s, ax, ay, az, bx, tilt)) * inv2h;
+    const T cp = mp_fma(-s, TiltFd<T>::sh, c * TiltFd<T>::ch), sp = mp_fma(c, TiltFd<T>::sh, s * TiltFd<T>::ch);
+    const T cm = mp_fma(s, TiltFd<T>::sh, c * TiltFd<T>::ch), sm = mp_fma(-c, TiltFd<T>::sh, s * TiltFd<T>::ch);
+    g3 = (tilt_value(px, py, pz, cp, sp, ax, ay, az, bx, tilt) - tilt_value(px, py, pz, cm, sm, ax, ay, az, bx, tilt)) * inv2h;
 }
 
 // fp32 record of a box for the bound pass: the box's world AABB as [lo, hi] per axis (rounded outwards);
@@ -471,7 +631,7 @@ __device__ __forceinline__ void pair_grad_local(const Pose<T> &p, T ax, T ay, T 
 // ---- point model -----------------------------------------------------------------------
 template <typename T>
 __device__ __forceinline__ T point_distance(T px, T py, T pz, const BoxRec<T> *__restrict__ boxes, int nb, T radius,
-                                             bool rot, int &arg_box)
+                                             bool rot, const T *__restrict__ tilt, int &arg_box)
 {
     T out2 = Lim<T>::inf(), in = Lim<T>::inf();
     int iout = -1, iin = -1;
@@ -481,13 +641,20 @@ __device__ __forceinline__ T point_distance(T px, T py, T pz, const BoxRec<T> *_
     for (int b = 0; b < nb; ++b) {
         const BoxRec<T> bx = nxt;
         nxt = load_box_uniform(boxes, b + 1 < nb ? b + 1 : b);
-        T ex = px - bx.cx, ey = py - bx.cy;
+        T ex = px - bx.cx, ey = py - bx.cy, ez = pz - bx.cz;
         if (rot) {
-            const T exw = ex, eyw = ey;
-            ex = mp_fma(bx.sb, eyw, bx.cb * exw);
-            ey = mp_fma(bx.cb, eyw, -(bx.sb * exw));
+            const T exw = ex, eyw = ey, ezw = ez;
+            if (tilt && bx.sb == T(2)) {   // e = R^T (p - c)
+                const T *R = tilt + 9 * (int)bx.cb;
+                ex = mp_fma(R[6], ezw, mp_fma(R[3], eyw, R[0] * exw));
+                ey = mp_fma(R[7], ezw, mp_fma(R[4], eyw, R[1] * exw));
+                ez = mp_fma(R[8], ezw, mp_fma(R[5], eyw, R[2] * exw));
+            } else {
+                ex = mp_fma(bx.sb, eyw, bx.cb * exw);
+                ey = mp_fma(bx.cb, eyw, -(bx.sb * exw));
+            }
         }
-        T qx = mp_abs(ex) - bx.hx, qy = mp_abs(ey) - bx.hy, qz = mp_abs(pz - bx.cz) - bx.hz;
+        T qx = mp_abs(ex) - bx.hx, qy = mp_abs(ey) - bx.hy, qz = mp_abs(ez) - bx.hz;
         bool outside = qx > T(0) || qy > T(0) || qz > T(0);
         T mx = mp_max(qx, T(0)), my = mp_max(qy, T(0)), mz = mp_max(qz, T(0));
         T v = mp_fma(mz, mz, mp_fma(my, my, mx * mx));
@@ -505,10 +672,18 @@ __device__ __forceinline__ T point_distance(T px, T py, T pz, const BoxRec<T> *_
 }
 
 template <typename T>
-__device__ __forceinline__ void point_grad(T px, T py, T pz, const BoxRec<T> bx, bool rot, T &g0, T &g1, T &g2)
+__device__ __forceinline__ void point_grad(T px, T py, T pz, const BoxRec<T> bx, bool rot, const T *__restrict__ tilt,
+                                            T &g0, T &g1, T &g2)
 {
     T ex = px - bx.cx, ey = py - bx.cy, ez = pz - bx.cz;
-    if (rot) {
+    const bool tilted = rot && tilt && bx.sb == T(2);
+    if (tilted) {
+        const T *R = tilt + 9 * (int)bx.cb;
+        const T exw = ex, eyw = ey, ezw = ez;
+        ex = mp_fma(R[6], ezw, mp_fma(R[3], eyw, R[0] * exw));
+        ey = mp_fma(R[7], ezw, mp_fma(R[4], eyw, R[1] * exw));
+        ez = mp_fma(R[8], ezw, mp_fma(R[5], eyw, R[2] * exw));
+    } else if (rot) {
         const T exw = ex, eyw = ey;
         ex = mp_fma(bx.sb, eyw, bx.cb * exw);
         ey = mp_fma(bx.cb, eyw, -(bx.sb * exw));
@@ -530,7 +705,13 @@ __device__ __forceinline__ void point_grad(T px, T py, T pz, const BoxRec<T> bx,
         T sg = sgn(a == 0 ? ex : (a == 1 ? ey : ez));
         g0 = a == 0 ? sg : T(0); g1 = a == 1 ? sg : T(0); g2 = a == 2 ? sg : T(0);
     }
-    if (rot) {   // box frame -> world
+    if (tilted) {   // box frame -> world: g_w = R g_l
+        const T *R = tilt + 9 * (int)bx.cb;
+        const T l0 = g0, l1 = g1, l2 = g2;
+        g0 = mp_fma(R[2], l2, mp_fma(R[1], l1, R[0] * l0));
+        g1 = mp_fma(R[5], l2, mp_fma(R[4], l1, R[3] * l0));
+        g2 = mp_fma(R[8], l2, mp_fma(R[7], l1, R[6] * l0));
+    } else if (rot) {   // box frame -> world
         const T l0 = g0, l1 = g1;
         g0 = bx.cb * l0 - bx.sb * l1;
         g1 = bx.sb * l0 + bx.cb * l1;

@@ -64,6 +64,7 @@ template <typename T> struct EvalArgs {
     const T *tsched;
     const DevTask<T> *tasks;
     const BoxRec<T> *boxes;
+    const T *tilt;            // rotation matrices (9 values each) of the tilted boxes, indexed by their cb field; or NULL
     const BoxRec32 *boxes32;  // fp32 bound-pass table, sorted along a Morton curve per task; pad0 = original index
     const BoxRec32 *groups;   // per group of consecutive sorted boxes two records: [2g] AABB, pad0/pad1 = first / count;
                               // [2g+1] centre of a representative box of the group
@@ -108,7 +109,7 @@ __host__ __device__ inline int lds_bytes_per_wave(int S, int e, bool grad)
 // first slot.  SEED: start from an upper bound taken from one representative box per group (used by the split
 // kernel, which serves every scene large enough to have groups).  On return MINKEY[slot] holds the ordered key of the scene value, ARG[slot] the deciding box
 // (-1: none) and CC/SS the (cos, sin) of the sample's yaw.
-template <typename T, bool ROT, bool LOCAL, bool SEED>
+template <typename T, int ROT, bool LOCAL, bool SEED>
 __device__ __forceinline__ void clearance_chunk(const EvalArgs<T> &a, const BoxRec<T> *boxes, const BoxRec32 *boxes32,
                                                 const BoxRec32 *groups, int ngroups, int n_wide, int lane, int k0, int Sp, const T *P0,
                                                 const T *P1, const T *P2, const T *YW, T *CC, T *SS,
@@ -169,17 +170,23 @@ __device__ __forceinline__ void clearance_chunk(const EvalArgs<T> &a, const BoxR
             const int ss = LOCAL ? kk : sample_of(a, k0 + kk);
             const BoxRec<T> bx = boxes[bb];
             T qx = P0[ss], qy = P1[ss], qc = CC[kk], qs = SS[kk], bcx = bx.cx, bcy = bx.cy;
-            if (ROT) {   // evaluate the pair in the box's own frame
-                to_box_frame(bx, qx, qy, qc, qs);
-                bcx = T(0); bcy = T(0);
+            if (ROT == 2 && box_is_tilted(bx)) {   // general rotation: the (large, rare) exact OBB routine
+                key = tilt_key(qx, qy, P2[ss], qc, qs, a.ax, a.ay, a.az, bx, a.tilt);
+            } else {
+                if (ROT) {   // evaluate the pair in the box's own frame
+                    to_box_frame(bx, qx, qy, qc, qs);
+                    bcx = T(0); bcy = T(0);
+                }
+                Pose<T> ps;
+                pose_setup(ps, qx, qy, P2[ss], qc, qs, a.ax, a.ay);
+                key = pair_key(ps, a.ax, a.ay, a.az, bcx, bcy, bx.cz, bx.hx, bx.hy, bx.hz);
             }
-            Pose<T> ps;
-            pose_setup(ps, qx, qy, P2[ss], qc, qs, a.ax, a.ay);
-            key = pair_key(ps, a.ax, a.ay, a.az, bcx, bcy, bx.cz, bx.hx, bx.hy, bx.hz);
 #ifdef MP_STATS
-            {   // how many evaluated pairs needed the rectangle distance (xy-separated), how many were overlaps
+            if (ROT == 0) {   // how many evaluated pairs needed the rectangle distance (xy-separated), how many were overlaps
+                Pose<T> pst;
+                pose_setup(pst, qx, qy, P2[ss], qc, qs, a.ax, a.ay);
                 PairOut<T> po;
-                pair_axes(ps, a.ax, a.ay, a.az, bcx, bcy, bx.cz, bx.hx, bx.hy, bx.hz, po);
+                pair_axes(pst, a.ax, a.ay, a.az, bcx, bcy, bx.cz, bx.hx, bx.hy, bx.hz, po);
                 if (po.gsat > T(0)) atomicAdd(&g_stats[5], 1ull);
                 if (!(po.gsat > T(0)) && !(po.gz > T(0))) atomicAdd(&g_stats[6], 1ull);
             }
@@ -264,14 +271,18 @@ __device__ __forceinline__ void clearance_chunk(const EvalArgs<T> &a, const BoxR
     wave_lds_sync();
 }
 
-// ROT: the scene holds yaw-rotated static boxes (a separate instantiation keeps the axis-aligned code as it was)
+// ROT: 0 axis-aligned scene; 1 the scene holds yaw-rotated static boxes; 2 it also holds tilted ones (separate
+// instantiations keep the axis-aligned code as it was)
 // PRE: split mode, the clearance profile comes from clearance_kernel (box model only)
 // Waves per SIMD the register budget is sized for: the fp64 gradient kernels need ~168 VGPRs (3 waves), every fp32
 // kernel and the fp64 cost-only kernels fit 128 (4 waves; the CEM populations run on those).
-template <typename T, bool GRAD> constexpr int eval_min_waves() { return (sizeof(T) == 8 && GRAD) ? MP_MIN_WAVES : MP_MIN_WAVES + 1; }
+template <typename T, bool GRAD, int ROT = 0> constexpr int eval_min_waves()
+{
+    return ROT == 2 ? 2 : ((sizeof(T) == 8 && GRAD) ? MP_MIN_WAVES : MP_MIN_WAVES + 1);   // the tilt routine is a real call: its registers count too
+}
 
-template <typename T, int MODEL, bool GRAD, bool ROT, bool PRE>
-__global__ void __launch_bounds__(256, (eval_min_waves<T, GRAD>())) eval_kernel(const EvalArgs<T> a)
+template <typename T, int MODEL, bool GRAD, int ROT, bool PRE>
+__global__ void __launch_bounds__(256, (eval_min_waves<T, GRAD, ROT>())) eval_kernel(const EvalArgs<T> a)
 {
     extern __shared__ __align__(16) unsigned char smem_raw[];
     const int lane = threadIdx.x & 63;
@@ -464,7 +475,7 @@ __global__ void __launch_bounds__(256, (eval_min_waves<T, GRAD>())) eval_kernel(
             for (int k = lane; k < Sp; k += 64) {
                 const int s = sample_of(a, k);
                 int arg = -1;
-                const T d = point_distance(P0[s], P1[s], P2[s], boxes, nb, a.radius, ROT, arg);
+                const T d = point_distance(P0[s], P1[s], P2[s], boxes, nb, a.radius, ROT != 0, ROT == 2 ? a.tilt : nullptr, arg);
                 Dd[k] = d;
                 ARG[k] = arg;
                 if (a.dist) a.dist[cand * a.Sp + k] = d;
@@ -646,12 +657,15 @@ __global__ void __launch_bounds__(256, (eval_min_waves<T, GRAD>())) eval_kernel(
                     const BoxRec<T> bx = boxes[arg];
                     if (MODEL == 1) {
                         T g0, g1, g2, g3;
-                        pair_grad(P0[s], P1[s], P2[s], CC[k], SS[k], a.ax, a.ay, a.az, bx, ROT, g0, g1, g2, g3);
+                        if (ROT == 2 && box_is_tilted(bx))
+                            tilt_grad(P0[s], P1[s], P2[s], CC[k], SS[k], a.ax, a.ay, a.az, bx, a.tilt, g0, g1, g2, g3);
+                        else
+                            pair_grad(P0[s], P1[s], P2[s], CC[k], SS[k], a.ax, a.ay, a.az, bx, ROT != 0, g0, g1, g2, g3);
                         G0[s] = gd * g0; G1[s] = gd * g1; G2[s] = gd * g2;
                         GY[s] = gd * g3 * DEG2RAD;
                     } else {
                         T g0, g1, g2;
-                        point_grad(P0[s], P1[s], P2[s], bx, ROT, g0, g1, g2);
+                        point_grad(P0[s], P1[s], P2[s], bx, ROT != 0, ROT == 2 ? a.tilt : nullptr, g0, g1, g2);
                         G0[s] = gd * g0; G1[s] = gd * g1; G2[s] = gd * g2;
                     }
                 }
@@ -771,7 +785,7 @@ __host__ __device__ inline int clearance_lds_bytes_per_wave(int e)
     return (64 + 6 * 64) * e + 8 * 64 + 4 * 64 + 4 * 128;   // W | P0 P1 P2 YW CC SS | MINKEY | ARG | QUEUE
 }
 
-template <typename T, bool ROT>
+template <typename T, int ROT>
 __global__ void __launch_bounds__(256) clearance_kernel(const EvalArgs<T> a)
 {
     extern __shared__ __align__(16) unsigned char smem_raw[];
@@ -853,18 +867,18 @@ __global__ void __launch_bounds__(256) clearance_kernel(const EvalArgs<T> a)
 template <typename T>
 __global__ void __launch_bounds__(256) point_sdf_kernel(long long n, const T *__restrict__ pts,
                                                          const BoxRec<T> *__restrict__ boxes, int nb, T radius,
-                                                         int has_rot, T *__restrict__ out)
+                                                         int has_rot, const T *__restrict__ tilt, T *__restrict__ out)
 {
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
         int arg;
-        out[i] = point_distance(pts[3 * i], pts[3 * i + 1], pts[3 * i + 2], boxes, nb, radius, has_rot != 0, arg);
+        out[i] = point_distance(pts[3 * i], pts[3 * i + 1], pts[3 * i + 2], boxes, nb, radius, has_rot != 0, tilt, arg);
     }
 }
 
 template <typename T>
 __global__ void __launch_bounds__(256) box_sdf_kernel(long long n, const T *__restrict__ pos, const T *__restrict__ yaw,
                                                        const BoxRec<T> *__restrict__ boxes, int nb, T ax, T ay, T az,
-                                                       T *__restrict__ out)
+                                                       const T *__restrict__ tilt, T *__restrict__ out)
 {
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
         T c, s;
@@ -872,7 +886,7 @@ __global__ void __launch_bounds__(256) box_sdf_kernel(long long n, const T *__re
         Pose<T> ps;
         pose_setup(ps, pos[3 * i], pos[3 * i + 1], pos[3 * i + 2], c, s, ax, ay);
         int arg;
-        out[i] = pose_distance(ps, ax, ay, az, boxes, nb, arg);
+        out[i] = pose_distance(ps, ax, ay, az, boxes, nb, tilt, arg);
     }
 }
 

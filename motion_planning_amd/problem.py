@@ -52,45 +52,64 @@ def goal_normal_resultant(goal_normals) -> Tuple[np.ndarray, bool]:
     return s, True
 
 
-def as_boxes8(boxes) -> np.ndarray:
-    """(B,6) axis-aligned rows or (B,8) rows -> contiguous float64 (B,8) rows
-    cx,cy,cz,hx,hy,hz,qz,qw  (qz, qw = z and w of the box's yaw-only quaternion; identity = 0, 1)."""
+def as_boxes10(boxes) -> np.ndarray:
+    """Any accepted row format -> contiguous float64 (B,10) rows cx,cy,cz,hx,hy,hz,qx,qy,qz,qw (quaternion of the
+    box's rotation, identity = 0,0,0,1): (B,6) axis aligned; (B,8) with the (z, w) of a yaw-only quaternion
+    appended; (B,10) with the full unit quaternion."""
     b = np.asarray(boxes, dtype=np.float64)
     if b.size == 0:
-        return np.zeros((0, 8), dtype=np.float64)
+        return np.zeros((0, 10), dtype=np.float64)
     b = np.atleast_2d(b)
+    n = b.shape[0]
     if b.shape[1] == 6:
-        b = np.hstack([b, np.zeros((b.shape[0], 1)), np.ones((b.shape[0], 1))])
-    if b.shape[1] != 8:
-        raise ValueError("box rows must have 6 or 8 columns")
+        b = np.hstack([b, np.zeros((n, 3)), np.ones((n, 1))])
+    elif b.shape[1] == 8:
+        b = np.hstack([b[:, :6], np.zeros((n, 2)), b[:, 6:8]])
+    elif b.shape[1] != 10:
+        raise ValueError("box rows must have 6, 8 or 10 columns")
     return np.ascontiguousarray(b)
+
+
+def as_boxes8(boxes) -> np.ndarray:
+    """(B,6) or (B,8) rows -> (B,8) rows cx,cy,cz,hx,hy,hz,qz,qw (yaw-only scenes; kept for callers of the 8-column form)."""
+    b = as_boxes10(boxes)
+    if np.any(b[:, 6] != 0.0) or np.any(b[:, 7] != 0.0):
+        raise ValueError("tilted boxes need the 10-column form")
+    return np.ascontiguousarray(np.hstack([b[:, :6], b[:, 8:10]]))
 
 
 def scene_to_boxes(scene, ignore_ids: Optional[Sequence[str]] = None) -> np.ndarray:
     """SoA export of a duck-typed scene: rows (cx,cy,cz,hx,hy,hz) of every block that is
     not ignored (geom/scene.py:88-95).  If any static block is rotated about z, the rows get two
-    more columns, the z and w of its quaternion (geom/blocks.py:8-21 keeps ``quat`` as [x,y,z,w]);
-    blocks tilted out of the horizontal plane are not supported."""
+    more columns, the z and w of its quaternion (geom/blocks.py:8-21 keeps ``quat`` as [x,y,z,w]); if any
+    block is tilted out of the horizontal plane, four more: the whole quaternion."""
     ignore = set(ignore_ids or [])
     rows: List[List[float]] = []
-    rotated = False
+    rotated = tilted = False
     for b in getattr(scene, "blocks", []):
         oid = getattr(b, "object_id", None)
         if oid is not None and oid in ignore:
             continue
         q = tuple(float(v) for v in getattr(b, "quat", (0.0, 0.0, 0.0, 1.0)))
-        if not (q[0] == 0.0 and q[1] == 0.0):
-            raise NotImplementedError("static blocks tilted about x or y are not supported (yaw-only rotations are)")
-        if abs(q[2] * q[2] + q[3] * q[3] - 1.0) > 1e-9:
+        if abs(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3] - 1.0) > 1e-9:
             raise ValueError("static block quaternion is not of unit length")
-        rotated = rotated or q[2] != 0.0
+        if q[0] != 0.0 or q[1] != 0.0:
+            tilted = True
+        elif q[2] != 0.0:
+            rotated = True
+        else:
+            q = (0.0, 0.0, 0.0, 1.0)   # w = -1 is the identity too
         sx, sy, sz = (float(v) for v in b.size)
         px, py, pz = (float(v) for v in b.position)
-        rows.append([px, py, pz, 0.5 * sx, 0.5 * sy, 0.5 * sz, q[2], q[3] if q[2] != 0.0 else 1.0])
+        rows.append([px, py, pz, 0.5 * sx, 0.5 * sy, 0.5 * sz, q[0], q[1], q[2], q[3]])
     if not rows:
         return np.zeros((0, 6), dtype=np.float64)
     arr = np.ascontiguousarray(np.asarray(rows, dtype=np.float64))
-    return arr if rotated else np.ascontiguousarray(arr[:, :6])
+    if tilted:
+        return arr
+    if rotated:
+        return np.ascontiguousarray(np.hstack([arr[:, :6], arr[:, 8:10]]))
+    return np.ascontiguousarray(arr[:, :6])
 
 
 @dataclass
@@ -128,7 +147,7 @@ class PathProblem:
     goal_normal: np.ndarray
     has_goal_normal: bool
     yaw_increasing: bool
-    boxes: np.ndarray           # (B,6) axis aligned, or (B,8) with (qz, qw) of each box's yaw quaternion
+    boxes: np.ndarray           # (B,6) axis aligned, (B,8) with (qz, qw) of each box's yaw quaternion, or (B,10) with (qx,qy,qz,qw)
     x0: np.ndarray
     sigma0: np.ndarray
     combined_4d: bool = True

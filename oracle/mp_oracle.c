@@ -183,10 +183,16 @@ typedef struct {
  * A yaw-rotated static box is handled by expressing the pair in the box frame: relative position
  * R_b^T (p - c_b) and relative rotation theta_a - theta_b; distances are invariant.  For cb = 1,
  * sb = 0 every expression below reduces bit-for-bit to the axis-aligned formulas. */
-#define BOX_STRIDE 8
+/* A box tilted out of the horizontal plane (general unit quaternion) carries sb = 2 and its rotation matrix
+ * R (world <- box, row major) in b[9..17]; it goes through tilt_eval below. */
+#define BOX_STRIDE 18
+#define BOX_IS_TILTED(b) ((b)[7] == RL(2.0))
+
+static void tilt_eval(const pose_t *pw, const real *b, pair_t *o);
 
 static void pair_eval(const pose_t *pw, const real *b, pair_t *o)
 {
+    if (BOX_IS_TILTED(b)) { tilt_eval(pw, b, o); return; }
     const real cb = b[6], sb = b[7];
     const real a3[3] = {pw->ax, pw->ay, pw->az};
     real dxw = pw->px - b[0], dyw = pw->py - b[1];
@@ -243,6 +249,134 @@ static void pair_eval(const pose_t *pw, const real *b, pair_t *o)
     }
 }
 
+
+/* ------------------------------------------------------------------------------
+ * General static box (any rotation) against the yaw-rotated mover — exact geometry:
+ *   overlapping: minus the smallest overlap over the 15 SAT axes (3 + 3 face normals, 9 edge cross products);
+ *   separated:   the smallest of 8 + 8 vertex-to-box and 12 x 12 edge-to-edge squared distances.
+ * For two boxes that share the z axis this is the same value as the yaw-only path (the extra axes and
+ * features coincide with the ones used there).  Everything is evaluated in the box's own frame.
+ * ---------------------------------------------------------------------------- */
+static real dot3f(const real *u, const real *v) { return FMA(u[2], v[2], FMA(u[1], v[1], u[0] * v[0])); }
+
+static real point_box_d2(const real *v, const real *h)
+{
+    real q0 = FABS(v[0]) - h[0], q1 = FABS(v[1]) - h[1], q2 = FABS(v[2]) - h[2];
+    real m0 = q0 > RL(0.0) ? q0 : RL(0.0), m1 = q1 > RL(0.0) ? q1 : RL(0.0), m2 = q2 > RL(0.0) ? q2 : RL(0.0);
+    return FMA(m2, m2, FMA(m1, m1, m0 * m0));
+}
+
+static real clamp01(real v) { return v < RL(0.0) ? RL(0.0) : (v > RL(1.0) ? RL(1.0) : v); }
+
+/* squared distance between segments P1 + s d1 and P2 + t d2, s, t in [0, 1] (both of non-zero length) */
+static real seg_seg_d2(const real *P1, const real *d1, const real *P2, const real *d2)
+{
+    real r[3] = {P1[0] - P2[0], P1[1] - P2[1], P1[2] - P2[2]};
+    real a = dot3f(d1, d1), e = dot3f(d2, d2), f = dot3f(d2, r), c = dot3f(d1, r), bb = dot3f(d1, d2);
+    real denom = a * e - bb * bb;
+    real sp = RL(0.0), tp;
+    if (denom > RL(0.0)) sp = clamp01((bb * f - c * e) / denom);
+    real tnom = FMA(bb, sp, f);
+    if (tnom < RL(0.0)) { tp = RL(0.0); sp = clamp01(-c / a); }
+    else if (tnom > e) { tp = RL(1.0); sp = clamp01((bb - c) / a); }
+    else tp = tnom / e;
+    real w[3];
+    for (int k = 0; k < 3; ++k) w[k] = FMA(-tp, d2[k], FMA(sp, d1[k], r[k]));
+    return dot3f(w, w);
+}
+
+static void tilt_eval(const pose_t *pw, const real *b, pair_t *o)
+{
+    const real *R = b + 9;
+    const real h[3] = {b[3], b[4], b[5]}, a[3] = {pw->ax, pw->ay, pw->az};
+    const real dw[3] = {pw->px - b[0], pw->py - b[1], pw->pz - b[2]};
+    real t[3], E[3][3]; /* E[k][i]: component k (box frame) of the mover's axis i */
+    for (int k = 0; k < 3; ++k) {
+        t[k] = FMA(R[6 + k], dw[2], FMA(R[3 + k], dw[1], R[k] * dw[0]));
+        E[k][0] = FMA(R[3 + k], pw->s, R[k] * pw->c);
+        E[k][1] = FMA(R[3 + k], pw->c, -(R[k] * pw->s));
+        E[k][2] = R[6 + k];
+    }
+    real e[3][3]; /* e[i] = mover axis i as a vector in the box frame */
+    for (int i = 0; i < 3; ++i)
+        for (int k = 0; k < 3; ++k) e[i][k] = E[k][i];
+    /* --- 15-axis SAT: largest signed gap --- */
+    real gmax = -INF_R;
+    for (int k = 0; k < 3; ++k) {
+        real ra = FMA(a[2], FABS(E[k][2]), FMA(a[1], FABS(E[k][1]), a[0] * FABS(E[k][0])));
+        real g = FABS(t[k]) - (h[k] + ra);
+        if (g > gmax) gmax = g;
+    }
+    for (int i = 0; i < 3; ++i) {
+        real rb = FMA(h[2], FABS(E[2][i]), FMA(h[1], FABS(E[1][i]), h[0] * FABS(E[0][i])));
+        real g = FABS(dot3f(t, e[i])) - (a[i] + rb);
+        if (g > gmax) gmax = g;
+    }
+    for (int i = 0; i < 3; ++i)
+        for (int k = 0; k < 3; ++k) {
+            /* L = e_i x u_k (u_k = unit vector k of the box frame) */
+            const int k1 = (k + 1) % 3, k2 = (k + 2) % 3;
+            real L[3];
+            L[k] = RL(0.0); L[k1] = -e[i][k2]; L[k2] = e[i][k1];
+            real n2 = dot3f(L, L);
+            if (!(n2 > RL(1e-12))) continue; /* parallel edges: the face normals decide */
+            real ra = FMA(a[2], FABS(dot3f(e[2], L)), FMA(a[1], FABS(dot3f(e[1], L)), a[0] * FABS(dot3f(e[0], L))));
+            real rb = FMA(h[2], FABS(L[2]), FMA(h[1], FABS(L[1]), h[0] * FABS(L[0])));
+            real g = (FABS(dot3f(t, L)) - (ra + rb)) / SQRT(n2);
+            if (g > gmax) gmax = g;
+        }
+    o->feature = -1;
+    o->gsat = gmax; o->gz = gmax;
+    if (!(gmax > RL(0.0))) {
+        o->separated = 0; o->v2 = RL(0.0); o->pen = gmax;
+        return;
+    }
+    /* --- separated: closest features --- */
+    real best = INF_R;
+    for (int m = 0; m < 8; ++m) { /* vertices of the mover against the box */
+        real sx = (m & 1) ? RL(1.0) : RL(-1.0), sy = (m & 2) ? RL(1.0) : RL(-1.0), sz = (m & 4) ? RL(1.0) : RL(-1.0);
+        real v[3];
+        for (int k = 0; k < 3; ++k) v[k] = FMA(sz * a[2], e[2][k], FMA(sy * a[1], e[1][k], FMA(sx * a[0], e[0][k], t[k])));
+        real d2 = point_box_d2(v, h);
+        if (d2 < best) best = d2;
+    }
+    for (int m = 0; m < 8; ++m) { /* vertices of the box against the mover (in the mover's frame) */
+        real u[3] = {((m & 1) ? h[0] : -h[0]) - t[0], ((m & 2) ? h[1] : -h[1]) - t[1], ((m & 4) ? h[2] : -h[2]) - t[2]};
+        real w[3] = {dot3f(u, e[0]), dot3f(u, e[1]), dot3f(u, e[2])};
+        real d2 = point_box_d2(w, a);
+        if (d2 < best) best = d2;
+    }
+    for (int i = 0; i < 3; ++i) { /* edges of the mover along its axis i ... */
+        const int i1 = (i + 1) % 3, i2 = (i + 2) % 3;
+        real d1[3] = {RL(2.0) * a[i] * e[i][0], RL(2.0) * a[i] * e[i][1], RL(2.0) * a[i] * e[i][2]};
+        for (int ma = 0; ma < 4; ++ma) {
+            real s1 = (ma & 1) ? a[i1] : -a[i1], s2 = (ma & 2) ? a[i2] : -a[i2];
+            real P1[3];
+            for (int k = 0; k < 3; ++k) P1[k] = FMA(s2, e[i2][k], FMA(s1, e[i1][k], FMA(-a[i], e[i][k], t[k])));
+            for (int k = 0; k < 3; ++k) { /* ... against the edges of the box along its axis k */
+                const int k1 = (k + 1) % 3, k2 = (k + 2) % 3;
+                real d2v[3] = {RL(0.0), RL(0.0), RL(0.0)};
+                d2v[k] = RL(2.0) * h[k];
+                for (int mb = 0; mb < 4; ++mb) {
+                    real P2[3];
+                    P2[k] = -h[k]; P2[k1] = (mb & 1) ? h[k1] : -h[k1]; P2[k2] = (mb & 2) ? h[k2] : -h[k2];
+                    real d2 = seg_seg_d2(P1, d1, P2, d2v);
+                    if (d2 < best) best = d2;
+                }
+            }
+        }
+    }
+    o->separated = 1; o->v2 = best; o->pen = RL(0.0);
+}
+
+/* value of one pair as a signed distance (used by the finite-difference gradient of tilted pairs) */
+static real pair_value(const pose_t *pw, const real *b)
+{
+    pair_t o;
+    pair_eval(pw, b, &o);
+    return o.separated ? SQRT(o.v2) : o.pen;
+}
+
 /* scene value for one pose: d = min over boxes, with the index of the deciding box */
 static real pose_distance(const pose_t *p, const real *boxes, int nb, int *arg_box)
 {
@@ -265,8 +399,43 @@ static real pose_distance(const pose_t *p, const real *boxes, int nb, int *arg_b
 /* partial derivatives of the pair distance w.r.t. (px,py,pz, theta[rad]) */
 static void pair_grad_local(const pair_t *po, const real *b, real g[4]);
 
+/* Tilted box: central differences of the exact pair value in (px, py, pz, theta) — the closed-form case
+ * analysis of the 160 features is not worth its size for boxes no shipped scenario contains. */
+#ifdef ORC_F32
+#define TILT_FD_H RL(2e-3)
+#define TILT_FD_COS RL(0.999998000000666666578)
+#define TILT_FD_SIN RL(0.00199999866666693333)
+#else
+#define TILT_FD_H RL(1e-6)
+#define TILT_FD_COS RL(0.9999999999995)
+#define TILT_FD_SIN RL(9.99999999999833333e-07)
+#endif
+static void tilt_grad(const pose_t *pw, const real *b, real g[4])
+{
+    const real a3[3] = {pw->ax, pw->ay, pw->az};
+    const real hh = TILT_FD_H, inv2h = RL(1.0) / (RL(2.0) * TILT_FD_H);
+    pose_t q;
+    real vp, vm;
+    pose_setup_cs(&q, pw->px + hh, pw->py, pw->pz, pw->c, pw->s, a3); vp = pair_value(&q, b);
+    pose_setup_cs(&q, pw->px - hh, pw->py, pw->pz, pw->c, pw->s, a3); vm = pair_value(&q, b);
+    g[0] = (vp - vm) * inv2h;
+    pose_setup_cs(&q, pw->px, pw->py + hh, pw->pz, pw->c, pw->s, a3); vp = pair_value(&q, b);
+    pose_setup_cs(&q, pw->px, pw->py - hh, pw->pz, pw->c, pw->s, a3); vm = pair_value(&q, b);
+    g[1] = (vp - vm) * inv2h;
+    pose_setup_cs(&q, pw->px, pw->py, pw->pz + hh, pw->c, pw->s, a3); vp = pair_value(&q, b);
+    pose_setup_cs(&q, pw->px, pw->py, pw->pz - hh, pw->c, pw->s, a3); vm = pair_value(&q, b);
+    g[2] = (vp - vm) * inv2h;
+    /* theta +- h: (c, s) rotated by +-h */
+    real cp = FMA(-pw->s, TILT_FD_SIN, pw->c * TILT_FD_COS), sp = FMA(pw->c, TILT_FD_SIN, pw->s * TILT_FD_COS);
+    real cm = FMA(pw->s, TILT_FD_SIN, pw->c * TILT_FD_COS), sm = FMA(-pw->c, TILT_FD_SIN, pw->s * TILT_FD_COS);
+    pose_setup_cs(&q, pw->px, pw->py, pw->pz, cp, sp, a3); vp = pair_value(&q, b);
+    pose_setup_cs(&q, pw->px, pw->py, pw->pz, cm, sm, a3); vm = pair_value(&q, b);
+    g[3] = (vp - vm) * inv2h;
+}
+
 static void pair_grad(const pose_t *pw, const real *b, real g[4])
 {
+    if (BOX_IS_TILTED(b)) { tilt_grad(pw, b, g); return; }
     pair_t o;
     pair_eval(pw, b, &o);
     pair_grad_local(&o, b, g);
@@ -340,9 +509,17 @@ static real point_distance(real px, real py, real pz, const real *boxes, int nb,
     int iout = -1, iin = -1;
     for (int b = 0; b < nb; ++b) {
         const real *bx = boxes + BOX_STRIDE * (size_t)b;
-        real exw = px - bx[0], eyw = py - bx[1];
-        real ex = FMA(bx[7], eyw, bx[6] * exw), ey = FMA(bx[6], eyw, -(bx[7] * exw));
-        real qx = FABS(ex) - bx[3], qy = FABS(ey) - bx[4], qz = FABS(pz - bx[2]) - bx[5];
+        real exw = px - bx[0], eyw = py - bx[1], ezw = pz - bx[2];
+        real ex, ey, ez;
+        if (BOX_IS_TILTED(bx)) { /* e = R^T (p - c) */
+            const real *R = bx + 9;
+            ex = FMA(R[6], ezw, FMA(R[3], eyw, R[0] * exw));
+            ey = FMA(R[7], ezw, FMA(R[4], eyw, R[1] * exw));
+            ez = FMA(R[8], ezw, FMA(R[5], eyw, R[2] * exw));
+        } else {
+            ex = FMA(bx[7], eyw, bx[6] * exw); ey = FMA(bx[6], eyw, -(bx[7] * exw)); ez = ezw;
+        }
+        real qx = FABS(ex) - bx[3], qy = FABS(ey) - bx[4], qz = FABS(ez) - bx[5];
         if (qx > RL(0.0) || qy > RL(0.0) || qz > RL(0.0)) {
             real mx = qx > RL(0.0) ? qx : RL(0.0), my = qy > RL(0.0) ? qy : RL(0.0),
                  mz = qz > RL(0.0) ? qz : RL(0.0);
@@ -360,8 +537,17 @@ static real point_distance(real px, real py, real pz, const real *boxes, int nb,
 
 static void point_grad(real px, real py, real pz, const real *bx, real g[3])
 {
-    real exw = px - bx[0], eyw = py - bx[1], ez = pz - bx[2];
-    real ex = FMA(bx[7], eyw, bx[6] * exw), ey = FMA(bx[6], eyw, -(bx[7] * exw));
+    real exw = px - bx[0], eyw = py - bx[1], ezw = pz - bx[2];
+    real ex, ey, ez;
+    const int tilted = BOX_IS_TILTED(bx);
+    if (tilted) {
+        const real *R = bx + 9;
+        ex = FMA(R[6], ezw, FMA(R[3], eyw, R[0] * exw));
+        ey = FMA(R[7], ezw, FMA(R[4], eyw, R[1] * exw));
+        ez = FMA(R[8], ezw, FMA(R[5], eyw, R[2] * exw));
+    } else {
+        ex = FMA(bx[7], eyw, bx[6] * exw); ey = FMA(bx[6], eyw, -(bx[7] * exw)); ez = ezw;
+    }
     real qx = FABS(ex) - bx[3], qy = FABS(ey) - bx[4], qz = FABS(ez) - bx[5];
     g[0] = g[1] = g[2] = RL(0.0);
     if (qx > RL(0.0) || qy > RL(0.0) || qz > RL(0.0)) {
@@ -376,7 +562,13 @@ static void point_grad(real px, real py, real pz, const real *bx, real g[3])
         if (qz > best) { best = qz; a = 2; }
         g[a] = sgn(a == 0 ? ex : a == 1 ? ey : ez);
     }
-    {   /* box frame -> world */
+    if (tilted) { /* box frame -> world: g_w = R g_l */
+        const real *R = bx + 9;
+        real l0 = g[0], l1 = g[1], l2 = g[2];
+        g[0] = FMA(R[2], l2, FMA(R[1], l1, R[0] * l0));
+        g[1] = FMA(R[5], l2, FMA(R[4], l1, R[3] * l0));
+        g[2] = FMA(R[8], l2, FMA(R[7], l1, R[6] * l0));
+    } else {   /* box frame -> world */
         real gx = bx[6] * g[0] - bx[7] * g[1], gy = bx[7] * g[0] + bx[6] * g[1];
         g[0] = gx; g[1] = gy;
     }
@@ -748,7 +940,7 @@ static void eval_one(const mp_config *cf, const mp_task *tk, const real *boxes, 
 }
 
 /* ------------------------------------------------------------------------------
- * Exported entry points (ctypes).  boxes8: [n_boxes x 8] = cx,cy,cz,hx,hy,hz,cos,sin doubles.
+ * Exported entry points (ctypes).  boxes8: [n_boxes x 18] doubles = cx,cy,cz, hx,hy,hz, cos,sin (sin = 2: tilted), spare, R[9] (row major, tilted boxes only).
  * cfg->basis / basis_yaw / t_sched must be non-NULL.
  * ---------------------------------------------------------------------------- */
 static real *to_real(const double *src, size_t n)

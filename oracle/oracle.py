@@ -78,7 +78,7 @@ def evaluate(
         tasks[i] = p.task_struct(box_begin=off, box_count=p.boxes.shape[0])
         boxes.append(p.boxes)
         off += p.boxes.shape[0]
-    boxes6 = np.ascontiguousarray(np.vstack([as_boxes8(b) for b in boxes])) if boxes else np.zeros((0, 8))
+    boxes6 = np.ascontiguousarray(np.vstack([as_boxes8(b) for b in boxes])) if boxes else np.zeros((0, 18))
     cost = np.empty(n, dtype=dt)
     terms = np.empty((n, abi.MP_NTERMS), dtype=dt)
     grad = np.empty((n, D), dtype=dt) if want_grad else None
@@ -96,23 +96,44 @@ def evaluate(
     return {"cost": cost, "terms": terms, "grad": grad, "min_clear": minc, "flags": flags, "dist": dist}
 
 
-def as_boxes8(boxes) -> np.ndarray:
-    """Box rows for the C oracle.  Input: (B,6) cx,cy,cz,hx,hy,hz (axis aligned) or (B,8) with the z and w
-    components of the box's yaw-only quaternion appended (the host-side row format of
-    motion_planning_amd.problem.scene_to_boxes).  Output: contiguous float64 (B,8) with (cos, sin) of the
-    box yaw in the last two columns, composed like the reference's quat_to_rot (geom/utils.py:3-14):
-    R00 = 1 - 2 zz, R10 = 2 wz."""
+def quat_rows(boxes) -> np.ndarray:
+    """Host row formats -> (B,10) rows cx,cy,cz,hx,hy,hz,qx,qy,qz,qw:
+    (B,6) axis aligned, (B,8) with the (z, w) of a yaw-only quaternion, (B,10) with a full unit quaternion."""
     b = np.asarray(boxes, dtype=np.float64)
     if b.size == 0:
-        return np.zeros((0, 8))
+        return np.zeros((0, 10))
     b = np.atleast_2d(b)
+    n = b.shape[0]
     if b.shape[1] == 6:
-        b = np.hstack([b, np.zeros((b.shape[0], 1)), np.ones((b.shape[0], 1))])
-    assert b.shape[1] == 8
-    out = b.copy()
-    z, w = b[:, 6], b[:, 7]
+        return np.hstack([b, np.zeros((n, 3)), np.ones((n, 1))])
+    if b.shape[1] == 8:
+        return np.hstack([b[:, :6], np.zeros((n, 2)), b[:, 6:8]])
+    assert b.shape[1] == 10
+    return b.copy()
+
+
+def as_boxes8(boxes) -> np.ndarray:
+    """Box rows for the C oracle: contiguous float64 (B,18) = cx,cy,cz, hx,hy,hz, cos,sin, spare, R[9].
+    Yaw-only boxes (x = y = 0 in the quaternion): (cos, sin) = (1 - 2zz, 2wz), the R00 / R10 of the reference's
+    quat_to_rot (geom/utils.py:3-14).  Any other rotation: sin = 2 marks the box as tilted and R holds the full
+    matrix of quat_to_rot, row major."""
+    q = quat_rows(boxes)
+    out = np.zeros((q.shape[0], 18))
+    out[:, :6] = q[:, :6]
+    x, y, z, w = q[:, 6], q[:, 7], q[:, 8], q[:, 9]
     out[:, 6] = 1.0 - 2.0 * (z * z)
     out[:, 7] = 2.0 * (w * z)
+    tilted = (x != 0.0) | (y != 0.0)
+    if np.any(tilted):
+        xx, yy, zz = x * x, y * y, z * z
+        xy, xz, yz = x * y, x * z, y * z
+        wx, wy, wz = w * x, w * y, w * z
+        R = np.stack([1 - 2 * (yy + zz), 2 * (xy - wz), 2 * (xz + wy),
+                      2 * (xy + wz), 1 - 2 * (xx + zz), 2 * (yz - wx),
+                      2 * (xz - wy), 2 * (yz + wx), 1 - 2 * (xx + yy)], axis=1)
+        out[tilted, 6] = 0.0
+        out[tilted, 7] = 2.0
+        out[tilted, 9:18] = R[tilted]
     return np.ascontiguousarray(out)
 
 

@@ -71,3 +71,28 @@ def with_rotated_statics(prob, seed=0, keep_first=True):
     rows[ang == 0.0, 6] = 0.0
     rows[ang == 0.0, 7] = 1.0
     return dataclasses.replace(prob, boxes=np.ascontiguousarray(rows))
+
+
+def with_tilted_statics(prob, seed=0, fraction=0.5, keep_first=True):
+    """Same problem with a share of the static boxes given a general rotation (10-column rows, full quaternion);
+    the others keep a yaw-only rotation or none."""
+    import dataclasses
+
+    from motion_planning_amd.problem import as_boxes10
+
+    rng = np.random.default_rng(seed)
+    rows = as_boxes10(prob.boxes).copy()
+    for i in range(rows.shape[0]):
+        if keep_first and i == 0:
+            continue
+        u = rng.random()
+        if u < fraction:
+            axis = rng.normal(size=3)
+            axis /= np.linalg.norm(axis)
+            h = 0.5 * np.radians(rng.uniform(-180.0, 180.0))
+            rows[i, 6:9] = np.sin(h) * axis
+            rows[i, 9] = np.cos(h)
+        elif u < fraction + 0.25:
+            h = 0.5 * np.radians(rng.uniform(-180.0, 180.0))
+            rows[i, 6:10] = [0.0, 0.0, np.sin(h), np.cos(h)]
+    return dataclasses.replace(prob, boxes=np.ascontiguousarray(rows))

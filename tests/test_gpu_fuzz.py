@@ -1,5 +1,5 @@
 """Randomised parity: planner configurations drawn at random (sample counts that are not multiples of the wave, up to
-14 vias, separate yaw spline, subsampled collision checks, every weight on or off, rotated static boxes, empty-ish and
+14 vias, separate yaw spline, subsampled collision checks, every weight on or off, rotated and tilted static boxes, empty-ish and
 cluttered scenes), HIP path through the C ABI against the CPU oracle.  Same bar as tests/test_gpu_parity.py."""
 import numpy as np
 import pytest
@@ -46,8 +46,11 @@ def _random_path_problem(rng, basis_fn):
     if box_model:
         kw["moving_block_size"] = tuple(rng.uniform(0.1, 0.9, 3))
     prob = build_path_problem(scene, start, goal, basis_fn, **kw)
-    if rng.random() < 0.35:
+    u = rng.random()
+    if u < 0.3:
         prob = H.with_rotated_statics(prob, seed=int(rng.integers(1 << 30)))
+    elif u < 0.5:
+        prob = H.with_tilted_statics(prob, seed=int(rng.integers(1 << 30)), fraction=float(rng.choice([0.1, 0.5, 1.0])))
     return prob
 
 

@@ -465,16 +465,15 @@ def test_rotated_static_boxes_large_scene_and_queries(native, oracle_lib):
     ctx.close()
 
 
-def test_tilted_static_box_is_refused(native):
+def test_scene_quaternion_validation(native):
     import ctypes as C
 
     ctx = native.Context(0)
     one = np.ones(1)
-    q = np.array([[np.sin(0.2), 0.0, 0.0, np.cos(0.2)]])
+    q = np.array([[np.sin(0.2), 0.0, 0.0, np.cos(0.2)]])           # tilted about x: accepted (general OBB routine)
     p = lambda a: a.ctypes.data_as(C.c_void_p)
-    rc = ctx.lib.mp_set_scene(ctx._h, 1, p(one), p(one), p(one), p(one), p(one), p(one), p(q))
-    assert rc == abi.MP_E_UNSUPPORTED
-    q = np.array([[0.0, 0.0, 0.5, 0.5]])
+    assert ctx.lib.mp_set_scene(ctx._h, 1, p(one), p(one), p(one), p(one), p(one), p(one), p(q)) == 0
+    q = np.array([[0.0, 0.0, 0.5, 0.5]])                           # not of unit length
     assert ctx.lib.mp_set_scene(ctx._h, 1, p(one), p(one), p(one), p(one), p(one), p(one), p(q)) == abi.MP_E_ARG
     ctx.close()
 
@@ -555,3 +554,43 @@ def test_new_scene_invalidates_the_problem(native):
     with pytest.raises(native.NativeError, match="mp_set_problem first"):
         ctx.eval(prob.x0[None, :])
     ctx.close()
+
+
+# ---- static boxes with a general rotation (tilted) -------------------------------------------
+@pytest.mark.parametrize("name", ["base_between", "synth50_seed0", "front_point", "vias_box_sub5"])
+def test_tilted_static_boxes_match_oracle(name, native, oracle_lib):
+    case = next(c for c in CASES if c["name"] == name)
+    prob = H.with_tilted_statics(H.problem_for_case(case), seed=31)
+    assert prob.boxes.shape[1] == 10
+    rng = np.random.default_rng(32)
+    X = np.vstack([G3[f"{name}__X"], prob.x0 + prob.sigma0 * rng.normal(size=(120, prob.dim))])
+    for dt in (np.float64, np.float32):
+        ctx = native.Context(0, dt)
+        ctx.set_problem(prob)
+        Xd = X.astype(dt)
+        out = ctx.eval(Xd, want_grad=True, want_dist=True)
+        ref = oracle_lib.evaluate(prob, Xd, dtype=dt)
+        _compare(out, ref, dt)
+        ctx.close()
+
+
+def test_tilted_static_boxes_queries_and_planner(native, oracle_lib):
+    from motion_planning_amd.problem import scene_to_boxes
+    from motion_planning_amd.scene import Scene
+
+    s = Scene()
+    s.add_block((2.0, 2.0, 0.1), (0.0, 0.0, 0.05), object_id="table")
+    h = np.radians(25.0) / 2
+    s.add_block((0.9, 0.3, 0.8), (0.1, 0.0, 0.6), quat=(np.sin(h), 0.0, 0.0, np.cos(h)), object_id="leaning_slab")
+    rows = scene_to_boxes(s)
+    assert rows.shape == (2, 10)
+    rng = np.random.default_rng(33)
+    pos = rng.uniform(-1, 1, (400, 3)) + np.array([0.0, 0.0, 0.8])
+    yaw = rng.uniform(-180, 180, 400)
+    for dt in (np.float64, np.float32):
+        ctx = native.Context(0, dt)
+        ctx.set_scene(rows)
+        np.testing.assert_array_equal(ctx.box_sdf((0.6, 0.4, 0.3), pos, yaw), oracle_lib.box_sdf(rows, (0.6, 0.4, 0.3), pos, yaw, dtype=dt))
+        np.testing.assert_array_equal(ctx.point_sdf(pos), oracle_lib.point_sdf(rows, pos, dtype=dt))
+        ctx.close()
+    assert s.signed_distance_block((0.6, 0.4, 0.3), (0.9, 0.0, 0.6)) == oracle_lib.box_sdf(rows, (0.6, 0.4, 0.3), np.array([[0.9, 0.0, 0.6]]), np.zeros(1))[0]

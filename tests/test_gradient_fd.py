@@ -59,3 +59,23 @@ def test_gradient_with_rotated_static_boxes(name, oracle_lib):
         assert np.abs(g - f1).max() <= 2e-5 * scale, (name, i, g, f1)
         good += 1
     assert good >= (X.shape[0] - 1) // 3, f"{name}: too few smooth points ({good}/{X.shape[0]})"
+
+
+@pytest.mark.parametrize("name", ["base_between", "synth50_seed0", "front_point"])
+def test_gradient_with_tilted_static_boxes(name, oracle_lib):
+    """Static boxes with a general rotation: pair gradients by central differences of the exact pair value (box model),
+    closed form through the box frame (point model)."""
+    prob = H.with_tilted_statics(H.problem_for_case(CASES[name]), seed=4)
+    assert prob.boxes.shape[1] == 10
+    X = H.load_g3()[f"{name}__X"]
+    out = oracle_lib.evaluate(prob, X)
+    good = 0
+    for i in range(1, X.shape[0]):
+        g = out["grad"][i]
+        f1, f2 = _fd(oracle_lib, prob, X[i], 1e-6), _fd(oracle_lib, prob, X[i], 2e-6)
+        scale = np.abs(g).max() + 1e-9
+        if np.abs(f1 - f2).max() > 1e-4 * scale:
+            continue
+        assert np.abs(g - f1).max() <= 5e-5 * scale, (name, i, g, f1)
+        good += 1
+    assert good >= (X.shape[0] - 1) // 3, f"{name}: too few smooth points ({good}/{X.shape[0]})"

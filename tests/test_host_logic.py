@@ -145,7 +145,7 @@ def test_with_vias_validation(oracle_lib):
 
 
 def test_static_block_rotations():
-    """Yaw-rotated static blocks export 8-column rows (z, w of the quaternion); tilted ones are refused."""
+    """Yaw-rotated static blocks export 8-column rows (z, w of the quaternion), tilted ones 10-column rows."""
     import math
 
     from motion_planning_amd.blocks import Block
@@ -157,8 +157,11 @@ def test_static_block_rotations():
     np.testing.assert_array_equal(rows[:, 6:], [[0.0, 1.0], [z, w]])
     assert scene_to_boxes(BoxList([Block((1, 1, 1), (0, 0, 0), quat=(0.0, 0.0, 0.0, -1.0))])).shape == (1, 6)
     np.testing.assert_array_equal(as_boxes8(np.zeros((2, 6)))[:, 6:], [[0.0, 1.0]] * 2)
-    with pytest.raises(NotImplementedError):
-        scene_to_boxes(BoxList([Block((1, 1, 1), (0, 0, 0), quat=(0.3826834323650898, 0.0, 0.0, 0.9238795325112867))]))
+    tilt = scene_to_boxes(BoxList([Block((1, 1, 1), (0, 0, 0)), Block((1, 1, 1), (2, 0, 0), quat=(0.3826834323650898, 0.0, 0.0, 0.9238795325112867))]))
+    assert tilt.shape == (2, 10)
+    np.testing.assert_array_equal(tilt[:, 6:], [[0.0, 0.0, 0.0, 1.0], [0.3826834323650898, 0.0, 0.0, 0.9238795325112867]])
+    with pytest.raises(ValueError):
+        as_boxes8(tilt)
     with pytest.raises(ValueError):
         scene_to_boxes(BoxList([Block((1, 1, 1), (0, 0, 0), quat=(0.0, 0.0, 0.5, 0.5))]))
 
