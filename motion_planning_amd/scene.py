@@ -12,8 +12,8 @@ from typing import Dict, List, Optional, Sequence, Tuple, Union
 import numpy as np
 
 from .blocks import Block
-from .problem import scene_to_boxes
-from .utils import quat_is_yaw_only, quat_to_rot, yaw_quat_to_deg
+from .problem import as_boxes10, scene_to_boxes
+from .utils import boxes_in_frame, quat_is_yaw_only, quat_to_rot, yaw_quat_to_deg
 
 IdLike = Union[int, str]
 
@@ -99,12 +99,22 @@ class Scene:
         return ctx.box_sdf(size, positions, np.ascontiguousarray(yaw))
 
     def signed_distance_block(self, size, position, quat=(0.0, 0.0, 0.0, 1.0), ignore_ids: Optional[List[str]] = None) -> float:
-        """Signed distance from a moving (yaw-rotated) box to the scene blocks (geom/scene.py:70-122):
-        positive = separated, 0 = touching, negative = minus the penetration depth."""
-        if not quat_is_yaw_only(quat):
-            raise NotImplementedError("only yaw rotations of the moving box are supported")
-        return float(self.signed_distance_block_many(size, np.asarray(position, dtype=float).reshape(1, 3),
-                                                     [yaw_quat_to_deg(quat)], ignore_ids)[0])
+        """Signed distance from a moving box to the scene blocks (geom/scene.py:70-122):
+        positive = separated, 0 = touching, negative = minus the penetration depth.
+
+        A yaw-only ``quat`` (what the planner produces) is one query against the resident scene.  Any other rotation
+        is answered in the moving box's own frame: the static boxes are re-expressed there on the host
+        (``utils.boxes_in_frame``) and the box, unrotated at the origin, is queried against them."""
+        if quat_is_yaw_only(quat):
+            return float(self.signed_distance_block_many(size, np.asarray(position, dtype=float).reshape(1, 3),
+                                                         [yaw_quat_to_deg(quat)], ignore_ids)[0])
+        rows = as_boxes10(scene_to_boxes(self, ignore_ids))
+        if rows.shape[0] == 0:
+            return float("inf")
+        ctx = self._native(ignore_ids)
+        ctx.set_scene(boxes_in_frame(rows, position, quat))
+        self._ctx_key = None   # the resident scene is now the transformed one
+        return float(ctx.box_sdf(size, np.zeros((1, 3)), np.zeros(1))[0])
 
     def sample_sdf_grid(self, bounds, dims):
         """Point SDF on a regular grid (geom/scene.py:157-170), one batched query."""
