@@ -334,6 +334,37 @@ template <typename T> int upload_problem(mp_ctx *ctx, const mp_task *tasks)
                     }
                     std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return code[x] < code[y]; });
                 }
+                // Visiting order of large scenes: whole groups of the Morton order nearest to the straight start -> goal line
+                // first, so that the running minimum of a lane tightens early and later boxes are culled by the bound.
+                // Any order gives the same result (minimum and lowest-index argmin are order independent).
+                {
+                    const double *A = tasks[i].ctrl[0], *B = tasks[i].ctrl[c.n_ctrl - 1];
+                    const double ab[3] = {B[0] - A[0], B[1] - A[1], B[2] - A[2]};
+                    const double ab2 = ab[0] * ab[0] + ab[1] * ab[1] + ab[2] * ab[2];
+                    auto line_gap = [&](int k) {   // centre-to-segment distance minus the half diagonal of the AABB
+                        const double *r = &ctx->h_boxes[(size_t)(b0 + k) * 6];
+                        double t = ab2 > 0.0 ? ((r[0] - A[0]) * ab[0] + (r[1] - A[1]) * ab[1] + (r[2] - A[2]) * ab[2]) / ab2 : 0.0;
+                        t = std::min(1.0, std::max(0.0, t));
+                        const double dx = r[0] - (A[0] + t * ab[0]), dy = r[1] - (A[1] + t * ab[1]), dz = r[2] - (A[2] + t * ab[2]);
+                        return std::sqrt(dx * dx + dy * dy + dz * dz) - std::sqrt(r[3] * r[3] + r[4] * r[4] + r[5] * r[5]);
+                    };
+                    // (small scenes keep the caller's order: measured, sorting 50 boxes by this key gains nothing for a
+                    // diffuse multi-start cloud, -1.5 % on config 3, and +4 % for converging CEM populations)
+                    if (cnt >= kGroupMin) {
+                        const int ng = (cnt + kGroup - 1) / kGroup;
+                        std::vector<double> gkey((size_t)ng, 1e300);
+                        for (int k = 0; k < cnt; ++k) gkey[(size_t)(k / kGroup)] = std::min(gkey[(size_t)(k / kGroup)], line_gap(order[(size_t)k]));
+                        std::vector<int> gord((size_t)ng);
+                        for (int g = 0; g < ng; ++g) gord[(size_t)g] = g;
+                        // the last (short) group stays last so that every other group is full
+                        std::stable_sort(gord.begin(), gord.end() - 1, [&](int x, int y) { return gkey[(size_t)x] < gkey[(size_t)y]; });
+                        std::vector<int> reordered;
+                        reordered.reserve((size_t)cnt);
+                        for (int g : gord)
+                            for (int k = g * kGroup; k < std::min(cnt, (g + 1) * kGroup); ++k) reordered.push_back(order[(size_t)k]);
+                        order.swap(reordered);
+                    }
+                }
                 const int sb0 = (int)sb.size(), g0 = (int)gr.size();
                 const int gsz = cnt >= kGroupMin ? kGroup : std::max(cnt, 1);
                 auto down = [](double v) { float f = (float)v; return (double)f > v ? std::nextafter(f, -INFINITY) : f; };
