@@ -61,6 +61,7 @@ struct mp_ctx {
     int max_task_boxes = 0;
     int idx_identity = 0;         // idx_safe is 0, 1, 2, ...
     int split_mode = -1;          // -1 automatic, 0 never, 1 always (MP_SPLIT_CLEARANCE, tuning aid)
+    int cem_graph = 1;            // replay the CEM generations from a captured HIP graph (MP_CEM_GRAPH=0 turns it off)
 
     // device-resident CEM
     DevBuf c_X, c_vals, c_minc, c_flags, c_mu, c_sigma, c_bestx, c_bestval, c_prev, c_bminc, c_bflags, c_done, c_nit,
@@ -556,9 +557,10 @@ int cem_solve(mp_ctx *ctx, long long n_inst, const int32_t *d_task, const T *d_x
     if ((rc = reserve(ctx, ctx->c_done, (size_t)n_inst))) return rc;
     if ((rc = reserve(ctx, ctx->c_nit, (size_t)n_inst * sizeof(int)))) return rc;
     if ((rc = reserve(ctx, ctx->c_active, 256))) return rc;
+    HIP_TRY(ctx, hipMemsetAsync(ctx->c_active.p, 0, 256, ctx->stream));   // [0] running count, [1] generation counter
     mp::CemState<T> st{(T *)ctx->c_mu.p, (T *)ctx->c_sigma.p, (T *)ctx->c_bestx.p, (T *)ctx->c_bestval.p,
                        (T *)ctx->c_prev.p, (T *)ctx->c_bminc.p, (uint8_t *)ctx->c_bflags.p, (uint8_t *)ctx->c_done.p,
-                       (int *)ctx->c_nit.p, (int *)ctx->c_active.p};
+                       (int *)ctx->c_nit.p, (int *)ctx->c_active.p, (int *)ctx->c_active.p + 1};
     const int eb = (int)std::min<long long>(((long long)nd + 255) / 256, (long long)ctx->num_cu * 8);
     hipLaunchKernelGGL(mp::cem_init_kernel<T>, dim3(std::max(eb, 1)), dim3(256), 0, ctx->stream, n_inst, D, st, d_x0, d_s0,
                        (T)o.min_sigma);
@@ -567,26 +569,69 @@ int cem_solve(mp_ctx *ctx, long long n_inst, const int32_t *d_task, const T *d_x
     const int wpb = 4;
     const int ub = (int)std::min<long long>((n_inst + wpb - 1) / wpb, (long long)ctx->num_cu * 16);
     const size_t ulds = (size_t)wpb * pop * sizeof(T);
-    for (int gen = 0; gen < o.max_iter; ++gen) {
-        const T *noise_g = d_noise ? d_noise + (size_t)gen * np_ * D : nullptr;
+    // one generation: sample, evaluate, tick (generation counter + running count), update — all on the stream
+    auto generation = [&](const T *noise_g) -> int {
         hipLaunchKernelGGL(mp::cem_sample_kernel<T>, dim3(sb), dim3(256), 0, ctx->stream, n_inst, pop, D, st, noise_g,
-                           (unsigned long long)o.seed, gen, (T *)ctx->c_X.p);
-        HIP_TRY(ctx, hipGetLastError());
-        if ((rc = launch_eval<T>(ctx, (long long)np_, ctx->c_X.p, nullptr, ctx->c_vals.p, nullptr, nullptr, ctx->c_minc.p,
-                                 (uint8_t *)ctx->c_flags.p, nullptr, pop, d_task, (const uint8_t *)ctx->c_done.p)))
-            return rc;
-        HIP_TRY(ctx, hipMemsetAsync(ctx->c_active.p, 0, sizeof(int), ctx->stream));
+                           (unsigned long long)o.seed, (T *)ctx->c_X.p);
+        if (hipGetLastError() != hipSuccess) return MP_E_HIP;
+        int r = launch_eval<T>(ctx, (long long)np_, ctx->c_X.p, nullptr, ctx->c_vals.p, nullptr, nullptr, ctx->c_minc.p,
+                               (uint8_t *)ctx->c_flags.p, nullptr, pop, d_task, (const uint8_t *)ctx->c_done.p);
+        if (r) return r;
+        hipLaunchKernelGGL(mp::cem_tick_kernel<T>, dim3(1), dim3(64), 0, ctx->stream, st);
         hipLaunchKernelGGL(mp::cem_update_kernel<T>, dim3(ub), dim3(64 * wpb), ulds, ctx->stream, n_inst, pop, D, n_elite,
                            (T)o.alpha, (T)o.min_sigma, (T)o.tol, st, (const T *)ctx->c_X.p, (const T *)ctx->c_vals.p,
                            (const T *)ctx->c_minc.p, (const uint8_t *)ctx->c_flags.p);
-        HIP_TRY(ctx, hipGetLastError());
-        if ((gen & 3) == 3 || gen + 1 == o.max_iter) {  // poll every 4 generations
+        return hipGetLastError() == hipSuccess ? MP_OK : MP_E_HIP;
+    };
+    auto still_running = [&](int &active) -> int {
+        HIP_TRY(ctx, hipMemcpyAsync(&active, ctx->c_active.p, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        return MP_OK;
+    };
+    int gen = 0;
+    if (o.max_iter > 0) {   // the first generation runs plainly: it performs every allocation the launches need
+        if ((rc = generation(d_noise))) return rc == MP_E_HIP ? fail(ctx, rc, "mp_cem_solve: kernel launch failed") : rc;
+        gen = 1;
+    }
+    // The launch-bound part of a small solve is the generation loop (four launches per generation): capture four
+    // generations into a HIP graph once and replay it; the host polls the running count after every replay.  Any
+    // failure to capture (e.g. the context is bound to the legacy default stream) falls back to plain launches;
+    // the results are the same either way.
+    constexpr int kGraphGens = 4;
+    hipGraphExec_t exec = nullptr;
+    if (!d_noise && ctx->cem_graph && o.max_iter >= 1 + 2 * kGraphGens) {
+        if (hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal) == hipSuccess) {
+            int crc = MP_OK;
+            for (int k = 0; k < kGraphGens && crc == MP_OK; ++k) crc = generation(nullptr);
+            hipGraph_t graph = nullptr;
+            const hipError_t ee = hipStreamEndCapture(ctx->stream, &graph);
+            if (crc == MP_OK && ee == hipSuccess && graph) {
+                if (hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) != hipSuccess) exec = nullptr;
+            }
+            if (graph) hipGraphDestroy(graph);
+        }
+        (void)hipGetLastError();   // a refused capture leaves a sticky error behind
+    }
+    bool stop = false;
+    while (gen < o.max_iter && !stop) {
+        if (exec && gen + kGraphGens <= o.max_iter) {
+            if (hipGraphLaunch(exec, ctx->stream) != hipSuccess) { hipGraphExecDestroy(exec); exec = nullptr; (void)hipGetLastError(); continue; }
+            gen += kGraphGens;
+        } else {
+            const T *noise_g = d_noise ? d_noise + (size_t)gen * np_ * D : nullptr;
+            if ((rc = generation(noise_g))) {
+                if (exec) hipGraphExecDestroy(exec);
+                return rc == MP_E_HIP ? fail(ctx, rc, "mp_cem_solve: kernel launch failed") : rc;
+            }
+            gen += 1;
+        }
+        if (exec || (gen & 3) == 0 || gen == o.max_iter) {   // poll the running count
             int active = 0;
-            HIP_TRY(ctx, hipMemcpyAsync(&active, ctx->c_active.p, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
-            HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-            if (active == 0) break;
+            if ((rc = still_running(active))) { if (exec) hipGraphExecDestroy(exec); return rc; }
+            stop = active == 0;
         }
     }
+    if (exec) hipGraphExecDestroy(exec);
     const hipMemcpyKind kind = mem == MP_MEM_HOST ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice;
     HIP_TRY(ctx, hipMemcpyAsync(best_x, ctx->c_bestx.p, nd * sizeof(T), kind, ctx->stream));
     HIP_TRY(ctx, hipMemcpyAsync(best_val, ctx->c_bestval.p, (size_t)n_inst * sizeof(T), kind, ctx->stream));
@@ -628,6 +673,7 @@ int mp_create(int device_id, int dtype, mp_ctx **out)
     mp_ctx *ctx = new mp_ctx();
     ctx->device = device_id;
     if (const char *sm = std::getenv("MP_SPLIT_CLEARANCE")) ctx->split_mode = std::atoi(sm) != 0 ? 1 : 0;
+    if (const char *cg = std::getenv("MP_CEM_GRAPH")) ctx->cem_graph = std::atoi(cg) != 0 ? 1 : 0;
     ctx->dtype = dtype;
     auto bail = [&](const char *what, hipError_t err) {
         fail(nullptr, MP_E_HIP, "mp_create: %s: %s", what, hipGetErrorString(err));

@@ -925,15 +925,17 @@ template <typename T> struct CemState {
     uint8_t *best_flags, *done;  // [n_inst]
     int *nit;                    // [n_inst]
     int *n_active;               // [1] instances still running after this generation
+    int *gen;                    // [1] generation counter (device resident, so that a captured graph can be replayed)
 };
 
 // X[i, p, :] = mu[i] + eps * sigma[i]; eps from `noise` (generation-major, parity mode) or Philox + Box-Muller
 template <typename T>
 __global__ void __launch_bounds__(256) cem_sample_kernel(long long n_inst, int pop, int D, CemState<T> st,
-                                                          const T *__restrict__ noise, unsigned long long seed, int gen,
+                                                          const T *__restrict__ noise, unsigned long long seed,
                                                           T *__restrict__ X)
 {
     const long long total = n_inst * pop * D;
+    const int gen = *st.gen;
     for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
         const long long inst = e / ((long long)pop * D);
         if (st.done[inst]) continue;
@@ -950,6 +952,12 @@ __global__ void __launch_bounds__(256) cem_sample_kernel(long long n_inst, int p
         }
         X[e] = st.mu[inst * D + d] + eps * st.sigma[inst * D + d];
     }
+}
+
+// between evaluation and update of a generation: advance the generation counter, clear the running count
+template <typename T> __global__ void cem_tick_kernel(CemState<T> st)
+{
+    if (blockIdx.x == 0 && threadIdx.x == 0) { *st.gen += 1; *st.n_active = 0; }
 }
 
 // one wave per instance: best-so-far, elite refit, stop rule
