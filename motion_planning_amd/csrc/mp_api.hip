@@ -10,6 +10,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <unordered_map>
 #include <vector>
 
 #include "../../include/mp_api.h"
@@ -287,13 +288,16 @@ template <typename T> int upload_problem(mp_ctx *ctx, const mp_task *tasks)
         constexpr int kGroup = 16, kGroupMin = 128;
         std::vector<mp::BoxRec32> sb, gr;
         std::vector<std::array<int, 6>> done;  // begin, count, sbox_begin, group_begin, group_count, n_wide
+        std::unordered_map<long long, size_t> done_at;   // (begin, count) -> index in done (10,000-task batches)
         auto as_float = [](int v) { float f; std::memcpy(&f, &v, 4); return f; };
         for (int i = 0; i < ctx->n_tasks; ++i) {
             const int b0 = tasks[i].box_begin;
             int cnt = tasks[i].box_count;
             const std::array<int, 6> *hit = nullptr;
-            for (const auto &d : done)
-                if (d[0] == b0 && d[1] == cnt) { hit = &d; break; }
+            {
+                const auto it = done_at.find(((long long)b0 << 32) | (unsigned int)cnt);
+                if (it != done_at.end()) hit = &done[it->second];
+            }
             if (!hit) {
                 // One "wide" box per range (a table, a floor: footprint at least twice the mover's circumradius each way,
                 // the largest one) goes first, outside the groups: the kernel settles its z-separated pairs without an
@@ -409,6 +413,7 @@ template <typename T> int upload_problem(mp_ctx *ctx, const mp_task *tasks)
                     gr.push_back(rep);
                 }
                 done.push_back({b0, cnt_all, sb0, g0 / 2, ((int)gr.size() - g0) / 2, n_wide});
+                done_at[((long long)b0 << 32) | (unsigned int)cnt_all] = done.size() - 1;
                 hit = &done.back();
             }
             dt[i].sbox_begin = (*hit)[2];
