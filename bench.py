@@ -7,7 +7,7 @@ fp64, full 15-term box-model objective + analytic gradient + min clearance + fla
 is one pass of the hot path over that batch (one mp_eval launch on HBM-resident inputs).
 Weak scaling: every rank owns its own 65,536 candidates (sharded by index), no data-path
 collective; the per-candidate (cost, min clearance, flags) of each step are all-gathered over
-RCCL asynchronously, overlapped with the next step.
+RCCL asynchronously straight from the kernel's output buffers (two output slots), overlapped with the next step.
 
   python bench.py --gpus 1 --steps 20 --warmup 3
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
@@ -125,24 +125,28 @@ def main():
     problem = synthetic_problem(_native.build_basis, N_BOXES, N_SAMPLES, seed=0)
     Xh = synthetic_candidates(problem, N_CAND, seed=100 + rank, dtype=np_dtype)   # this rank's index shard
     X = torch.from_numpy(Xh).cuda()
-    db = DeviceBatch(problem, N_CAND, device=local_rank, dtype=np_dtype, want_grad=True)
+    # two output slots: the collectives of step i read slot i % 2 while step i + 1 computes into the other one
+    dbs = [DeviceBatch(problem, N_CAND, device=local_rank, dtype=np_dtype, want_grad=True) for _ in range(2 if world > 1 else 1)]
+    db = dbs[0]
     # collectives run on device tensors over RCCL; the gloo rehearsal (one-GPU box) stages them through the host
     coll_dev = "cuda" if backend == "nccl" else "cpu"
-    gather_buf = [torch.empty(world * N_CAND, 3, dtype=tdtype, device=coll_dev) for _ in range(2)] if world > 1 else None
-    packed_buf = [torch.empty(N_CAND, 3, dtype=tdtype, device="cuda") for _ in range(2)] if world > 1 else None
+    if world > 1:
+        gather_val = [torch.empty(world * 2, N_CAND, dtype=tdtype, device=coll_dev) for _ in range(2)]
+        gather_flg = [torch.empty(world * N_CAND, dtype=torch.uint8, device=coll_dev) for _ in range(2)]
 
     def step(i, pending):
-        out = db.evaluate(X)
+        cur = dbs[i % len(dbs)]
+        if world > 1 and len(pending) >= 2:
+            for w in pending.pop(0):   # the collectives that read this slot two steps ago
+                w.wait()
+        out = cur.evaluate(X)
         if world > 1:
-            # double-buffered: the collective of step i runs on RCCL's stream while step i+1 computes
-            if len(pending) >= 2:
-                pending.pop(0).wait()
-            pk = packed_buf[i % 2]
-            pk[:, 0].copy_(out["cost"])
-            pk[:, 1].copy_(out["min_clear"])
-            pk[:, 2].copy_(out["flags"])
-            src = pk if coll_dev == "cuda" else pk.cpu()
-            pending.append(dist.all_gather_into_tensor(gather_buf[i % 2], src, async_op=True))
+            # the kernel's own output buffers go into the collectives (cost and min clearance are one tensor): no
+            # packing kernel; the gathers run on RCCL's stream while the next step computes into the other slot
+            val = cur.cost_minc if coll_dev == "cuda" else cur.cost_minc.cpu()
+            flg = cur.flags if coll_dev == "cuda" else cur.flags.cpu()
+            pending.append((dist.all_gather_into_tensor(gather_val[i % 2], val, async_op=True),
+                            dist.all_gather_into_tensor(gather_flg[i % 2], flg, async_op=True)))
         return out
 
     def sync():
@@ -154,15 +158,17 @@ def main():
     pend = []
     for i in range(args.warmup):
         step(i, pend)
-    for w in pend:
-        w.wait()
+    for ws in pend:
+        for w in ws:
+            w.wait()
     sync()
     pend = []
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(i, pend)
-    for w in pend:
-        w.wait()
+    for ws in pend:
+        for w in ws:
+            w.wait()
     sync()
     elapsed = time.perf_counter() - t0
     if world > 1:
@@ -286,7 +292,8 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(problem, Xh.astype(np.float64))
         print(json.dumps(line))
-    db.close()
+    for d in dbs:
+        d.close()
     if world > 1:
         dist.barrier()   # rank 0 prints and times the CPU baseline last; nobody tears the group down early
         dist.destroy_process_group()

@@ -52,8 +52,11 @@ class DeviceBatch:
         self._stream = -1   # no stream bound yet (0 is a valid handle: the default stream)
         dev = torch.device("cuda", self.device)
         D = self.problem.dim
-        self.cost = torch.empty(capacity, dtype=self.tdtype, device=dev)
-        self.min_clear = torch.empty(capacity, dtype=self.tdtype, device=dev)
+        # cost and min clearance are the two rows of one buffer, so that a job can all-gather both with one collective
+        # straight from the kernel's output (no packing kernel in between)
+        self.cost_minc = torch.empty(2, capacity, dtype=self.tdtype, device=dev)
+        self.cost = self.cost_minc[0]
+        self.min_clear = self.cost_minc[1]
         self.flags = torch.empty(capacity, dtype=torch.uint8, device=dev)
         self.grad = torch.empty(capacity, D, dtype=self.tdtype, device=dev) if want_grad else None
         self.terms = torch.empty(capacity, abi.MP_NTERMS, dtype=self.tdtype, device=dev) if want_terms else None
