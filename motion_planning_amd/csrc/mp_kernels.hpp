@@ -274,11 +274,13 @@ __device__ __forceinline__ void clearance_chunk(const EvalArgs<T> &a, const BoxR
 // ROT: 0 axis-aligned scene; 1 the scene holds yaw-rotated static boxes; 2 it also holds tilted ones (separate
 // instantiations keep the axis-aligned code as it was)
 // PRE: split mode, the clearance profile comes from clearance_kernel (box model only)
-// Waves per SIMD the register budget is sized for: the fp64 gradient kernels need ~168 VGPRs (3 waves), every fp32
-// kernel and the fp64 cost-only kernels fit 128 (4 waves; the CEM populations run on those).
+// Waves per SIMD the register budget is sized for (measured, config 3): fp64 gradient kernels 3 (168 VGPRs; 2 and 4
+// are both ~20 % slower), fp64 cost-only kernels 4 (127 VGPRs; the CEM populations run on those), fp32 kernels 5
+// (<= 102 VGPRs: -6 % against 4).
 template <typename T, bool GRAD, int ROT = 0> constexpr int eval_min_waves()
 {
-    return ROT == 2 ? 2 : ((sizeof(T) == 8 && GRAD) ? MP_MIN_WAVES : MP_MIN_WAVES + 1);   // the tilt routine is a real call: its registers count too
+    return ROT == 2 ? 2   // the tilt routine is a real call: its registers count too
+                    : (sizeof(T) == 4 ? MP_MIN_WAVES + 2 : (GRAD ? MP_MIN_WAVES : MP_MIN_WAVES + 1));
 }
 
 template <typename T, int MODEL, bool GRAD, int ROT, bool PRE>
