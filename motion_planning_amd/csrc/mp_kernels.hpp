@@ -754,7 +754,20 @@ __global__ void __launch_bounds__(256, (eval_min_waves<T, GRAD, ROT>())) eval_ke
                     const T *V = is_pos ? A1x + comp * S : A2x;
                     const T *Mc = is_pos ? a.M + ff + jj : a.My + 1 + jj;
                     const int ld = is_pos ? C : Cy;
-                    for (int sidx = sg8; sidx < S; sidx += 8) acc = mp_fma(Mc[(size_t)sidx * ld], V[sidx], acc);
+                    // eight (M, g) pairs fetched per trip, then the same in-order fma chain (a one-at-a-time loop
+                    // waits for every load in turn)
+                    for (int b0 = sg8; b0 < S; b0 += 64) {
+                        T mv[8], gv[8];
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) {
+                            const int sidx = b0 + 8 * u;
+                            const int sc = sidx < S ? sidx : S - 1;
+                            mv[u] = Mc[(size_t)sc * ld];
+                            gv[u] = sidx < S ? V[sc] : T(0);
+                        }
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) acc = mp_fma(mv[u], gv[u], acc);
+                    }
                 }
                 acc += dpp_mov<0xB1, 0xf, true>(acc);   // quad_perm [1,0,3,2]
                 acc += dpp_mov<0x4E, 0xf, true>(acc);   // quad_perm [2,3,0,1]
