@@ -90,6 +90,40 @@ template <typename T> __device__ __forceinline__ int sample_of(const EvalArgs<T>
     return a.idx_identity ? k : a.idx_safe[k];
 }
 
+// One spline sample Q[s] = M[s,:] W (positions) and My[s,:] W[:,3] (yaw): the oracle's fixed fma chain over the
+// waypoints.  Four waypoints (n_vias = 2, the reference's default everywhere) take a path of their own: the two rows
+// are 32 bytes each and are fetched whole before the chain starts; the general loop waits for one entry at a time.
+template <typename T> struct alignas(2 * sizeof(T)) Pair2 { T a, b; };
+
+template <typename T>
+__device__ __forceinline__ void spline_sample(const T *__restrict__ m, const T *__restrict__ my, int C, int Cy, const T *W,
+                                              T &px, T &py, T &pz, T &yw)
+{
+    if (C == 4 && Cy == 4) {
+        const Pair2<T> *r = reinterpret_cast<const Pair2<T> *>(m), *ry = reinterpret_cast<const Pair2<T> *>(my);
+        const Pair2<T> r0 = r[0], r1 = r[1], y0 = ry[0], y1 = ry[1];
+        px = r0.a * W[0]; py = r0.a * W[1]; pz = r0.a * W[2];
+        px = mp_fma(r0.b, W[4], px); py = mp_fma(r0.b, W[5], py); pz = mp_fma(r0.b, W[6], pz);
+        px = mp_fma(r1.a, W[8], px); py = mp_fma(r1.a, W[9], py); pz = mp_fma(r1.a, W[10], pz);
+        px = mp_fma(r1.b, W[12], px); py = mp_fma(r1.b, W[13], py); pz = mp_fma(r1.b, W[14], pz);
+        yw = y0.a * W[3];
+        yw = mp_fma(y0.b, W[7], yw);
+        yw = mp_fma(y1.a, W[11], yw);
+        yw = mp_fma(y1.b, W[15], yw);
+        return;
+    }
+    const T m0 = m[0];
+    px = m0 * W[0]; py = m0 * W[1]; pz = m0 * W[2];
+    for (int j = 1; j < C; ++j) {
+        const T mj = m[j];
+        px = mp_fma(mj, W[4 * j + 0], px);
+        py = mp_fma(mj, W[4 * j + 1], py);
+        pz = mp_fma(mj, W[4 * j + 2], pz);
+    }
+    yw = my[0] * W[3];
+    for (int j = 1; j < Cy; ++j) yw = mp_fma(my[j], W[4 * j + 3], yw);
+}
+
 // LDS slice of one wave (bytes).  Layout (S = samples, e = sizeof(T)):
 //   W[64] | P[3][S] YAW[S] | D[S] | CC[S] SS[S] | D1[3][S]                        (T; every launch: 10 arrays)
 //   | GP[3][S] GY[S] | GD[S] | A1[3][S] A2[3][S] | SEGW[S]                         (T; gradient launches: 12 more)
@@ -349,18 +383,8 @@ __global__ void __launch_bounds__(256, (eval_min_waves<T, GRAD, ROT>())) eval_ke
 
         // ---- spline samples Q = M W (fixed fma chain over the waypoints) ----
         for (int s = lane; s < S; s += 64) {
-            const T *m = a.M + (size_t)s * C;
-            T m0 = m[0];
-            T px = m0 * W[0], py = m0 * W[1], pz = m0 * W[2];
-            for (int j = 1; j < C; ++j) {
-                T mj = m[j];
-                px = mp_fma(mj, W[4 * j + 0], px);
-                py = mp_fma(mj, W[4 * j + 1], py);
-                pz = mp_fma(mj, W[4 * j + 2], pz);
-            }
-            const T *my = a.My + (size_t)s * Cy;
-            T yw = my[0] * W[3];
-            for (int j = 1; j < Cy; ++j) yw = mp_fma(my[j], W[4 * j + 3], yw);
+            T px, py, pz, yw;
+            spline_sample(a.M + (size_t)s * C, a.My + (size_t)s * Cy, C, Cy, W, px, py, pz, yw);
             P0[s] = px; P1[s] = py; P2[s] = pz; YW[s] = yw;
             if (GRAD) { G0[s] = T(0); G1[s] = T(0); G2[s] = T(0); GY[s] = T(0); }
         }
@@ -854,18 +878,8 @@ __global__ void __launch_bounds__(256) clearance_kernel(const EvalArgs<T> a)
         const int k = k0 + lane;
         if (k < a.Sp) {   // this lane's sample, same fma chain as eval_kernel
             const int s = sample_of(a, k);
-            const T *m = a.M + (size_t)s * C;
-            T m0 = m[0];
-            T px = m0 * W[0], py = m0 * W[1], pz = m0 * W[2];
-            for (int j = 1; j < C; ++j) {
-                T mj = m[j];
-                px = mp_fma(mj, W[4 * j + 0], px);
-                py = mp_fma(mj, W[4 * j + 1], py);
-                pz = mp_fma(mj, W[4 * j + 2], pz);
-            }
-            const T *my = a.My + (size_t)s * Cy;
-            T yw = my[0] * W[3];
-            for (int j = 1; j < Cy; ++j) yw = mp_fma(my[j], W[4 * j + 3], yw);
+            T px, py, pz, yw;
+            spline_sample(a.M + (size_t)s * C, a.My + (size_t)s * Cy, C, Cy, W, px, py, pz, yw);
             P0[lane] = px; P1[lane] = py; P2[lane] = pz; YW[lane] = yw;
         }
         wave_lds_sync();
