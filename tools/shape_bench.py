@@ -12,6 +12,8 @@ from motion_planning_amd.batch import DeviceBatch  # noqa: E402
 from motion_planning_amd.synthetic import synthetic_candidates, synthetic_problem  # noqa: E402
 
 shapes = [(50, 64, 65536), (50, 101, 32768), (13, 101, 65536), (200, 64, 32768), (2000, 64, 16384), (50, 256, 16384), (2000, 256, 16384)]
+if len(sys.argv) > 1:   # e.g. "50,64,65536;13,101,65536"
+    shapes = [tuple(int(v) for v in t.split(",")) for t in sys.argv[1].split(";")]
 for B, S, N in shapes:
     prob = synthetic_problem(_native.build_basis, B, S, seed=1 if B >= 1000 else 0, size_range=(0.05, 0.3) if B >= 1000 else (0.1, 0.6))
     X = torch.from_numpy(synthetic_candidates(prob, N, seed=5)).cuda()
