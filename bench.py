@@ -227,6 +227,23 @@ def main():
             db_o.evaluate(Xo)
         extras[("fp32" if args.dtype == "f64" else "fp64") + "_cost_grad_evals_per_s"] = N_CAND / (db_o.ctx.timer_stop() / args.steps * 1e-3)
         db_o.close()
+        if not args.no_cpu_baseline:
+            # independent batches pipelined over two streams (two contexts, two output slots): the next batch's
+            # ramp-up fills the tail of the previous one.  Side figure only; `value` and the roofline above are
+            # single-stream.  Skipped with --no-cpu-baseline (the rocprofv3 run), whose per-kernel average
+            # duration would otherwise mix overlapped launches of the same kernel in.
+            db2 = DeviceBatch(problem, N_CAND, dtype=np_dtype, want_grad=True)
+            pair, strs = [db, db2], [torch.cuda.Stream(), torch.cuda.Stream()]
+            for rep in range(2):
+                torch.cuda.synchronize()
+                tp = time.perf_counter()
+                for i in range(2 * args.steps):
+                    with torch.cuda.stream(strs[i % 2]):
+                        pair[i % 2].evaluate(X)
+                torch.cuda.synchronize()
+                tp = time.perf_counter() - tp
+            extras["two_streams_evals_per_s"] = 2 * args.steps * N_CAND / tp
+            db2.close()
         fl = db.flags.cpu().numpy()
         extras["colliding_fraction"] = float((fl & 1).mean())
         extras["feasible_fraction"] = float(((fl & 2) != 0).mean())
