@@ -129,6 +129,33 @@ def test_empty_and_ragged_inputs(native, oracle_lib):
     ctx.close()
 
 
+def test_non_finite_candidates_do_not_disturb_their_neighbours(native):
+    """NaN / Inf / huge entries in some candidates (an optimiser that stepped out of bounds): the call returns, and
+    every finite candidate of the batch gets exactly the result it gets in a clean batch (one wave per candidate,
+    nothing shared) - through the fused and the split clearance path, with and without gradient."""
+    from motion_planning_amd.synthetic import synthetic_candidates, synthetic_problem
+
+    for n_boxes, n_samples in ((50, 64), (200, 101)):
+        prob = synthetic_problem(native.build_basis, n_boxes=n_boxes, n_samples=n_samples, seed=0)
+        X = synthetic_candidates(prob, 512, seed=3)
+        bad = X.copy()
+        rows = np.arange(0, 512, 7)
+        bad[rows[0::4], 0] = np.nan
+        bad[rows[1::4], 3] = np.inf
+        bad[rows[2::4], -1] = -np.inf          # a yaw control
+        bad[rows[3::4], 1] = 1e300
+        good = np.setdiff1d(np.arange(512), rows)
+        ctx = native.Context(0)
+        ctx.set_problem(prob)
+        for grad in (True, False):
+            clean = ctx.eval(X, want_grad=grad, want_dist=True)
+            out = ctx.eval(bad, want_grad=grad, want_dist=True)
+            for key in ("cost", "min_clear", "flags", "dist") + (("grad",) if grad else ()):
+                np.testing.assert_array_equal(out[key][good], clean[key][good], err_msg=key)
+            assert not np.isfinite(out["cost"][rows[0::4]]).any()      # NaN in, no finite cost out
+        ctx.close()
+
+
 def test_error_paths(native):
     ctx = native.Context(0)
     prob = H.problem_for_case(CASES[0])
