@@ -156,6 +156,36 @@ def test_non_finite_candidates_do_not_disturb_their_neighbours(native):
         ctx.close()
 
 
+def test_contexts_on_concurrent_host_threads(native, oracle_lib):
+    """include/mp_api.h: a context is not re-entrant, different contexts are independent.  Four host threads, each
+    with a context, problem and stream of its own, evaluate at the same time (ctypes releases the GIL): every thread
+    gets the oracle's result for ITS problem."""
+    from concurrent.futures import ThreadPoolExecutor
+
+    from motion_planning_amd.synthetic import synthetic_candidates, synthetic_problem
+
+    shapes = [(50, 64), (13, 101), (200, 64), (3, 40)]
+    probs = [synthetic_problem(native.build_basis, n_boxes=b, n_samples=s, seed=i) for i, (b, s) in enumerate(shapes)]
+    Xs = [synthetic_candidates(p, 192, seed=20 + i) for i, p in enumerate(probs)]
+    refs = [oracle_lib.evaluate(p, X) for p, X in zip(probs, Xs)]
+
+    def work(i):
+        ctx = native.Context(0)
+        ctx.set_problem(probs[i])
+        outs = [ctx.eval(Xs[i], want_grad=True, want_dist=True) for _ in range(25)]
+        ctx.close()
+        return outs
+
+    with ThreadPoolExecutor(max_workers=4) as pool:
+        results = list(pool.map(work, range(4)))
+    for i, outs in enumerate(results):
+        for out in outs:
+            np.testing.assert_array_equal(out["dist"], refs[i]["dist"])
+            np.testing.assert_array_equal(out["flags"], refs[i]["flags"])
+            assert H.rel_err(out["cost"], refs[i]["cost"]).max() < 1e-9
+            assert _grad_err(out["grad"], refs[i]["grad"]) < 1e-9
+
+
 def test_error_paths(native):
     ctx = native.Context(0)
     prob = H.problem_for_case(CASES[0])
