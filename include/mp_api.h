@@ -154,7 +154,11 @@ int mp_api_version(void);
 /* Use an externally owned hipStream_t (e.g. torch's current stream) for all work of
  * this context.  The handle is used as given: NULL is HIP's default (null) stream, which
  * is what torch reports as its default stream on ROCm.  mp_use_own_stream() goes back to
- * the non-blocking stream the context created for itself. */
+ * the non-blocking stream the context created for itself.  Switching waits for the work
+ * queued on the previous stream, except when the new stream is being captured into a HIP
+ * graph (no synchronisation is allowed then; ordering is the capturing caller's business).
+ * MP_MEM_DEVICE calls of mp_eval can be captured: after one ordinary call of the same
+ * shape they neither allocate nor synchronise. */
 int mp_set_stream(mp_ctx *ctx, void *hip_stream);
 int mp_use_own_stream(mp_ctx *ctx);
 int mp_synchronize(mp_ctx *ctx);

@@ -727,7 +727,12 @@ int mp_set_stream(mp_ctx *ctx, void *hip_stream)
     if (rc) return rc;
     hipStream_t next = (hipStream_t)hip_stream;
     if (next == ctx->stream) return MP_OK;
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));  // work queued on the old stream finishes first
+    // Work queued on the old stream finishes first - unless the new stream is being captured into a graph: a
+    // synchronisation is not allowed then (it would invalidate the capture), and ordering against earlier work is the
+    // capturing caller's business (torch.cuda.graph waits for the side stream before it starts capturing).
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (next == nullptr || hipStreamIsCapturing(next, &cap) != hipSuccess) { (void)hipGetLastError(); cap = hipStreamCaptureStatusNone; }
+    if (cap == hipStreamCaptureStatusNone) HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     ctx->stream = next;
     return MP_OK;
 }

@@ -186,6 +186,40 @@ def test_contexts_on_concurrent_host_threads(native, oracle_lib):
             assert _grad_err(out["grad"], refs[i]["grad"]) < 1e-9
 
 
+def test_device_pointer_call_can_be_captured_into_a_graph(native):
+    """mp_eval(MP_MEM_DEVICE) on a stream under capture: after one call of the same shape nothing in it allocates or
+    synchronises, so it can be recorded into a HIP graph and replayed on new inputs (torch.cuda.graph drives the
+    capture; mp_set_stream must not synchronise while the new stream is capturing)."""
+    import torch
+
+    from motion_planning_amd.batch import DeviceBatch
+    from motion_planning_amd.synthetic import synthetic_candidates, synthetic_problem
+
+    prob = synthetic_problem(native.build_basis, 50, 64, seed=0)
+    n = 4096
+    X1 = torch.from_numpy(synthetic_candidates(prob, n, seed=5)).cuda()
+    X2 = torch.from_numpy(synthetic_candidates(prob, n, seed=6)).cuda()
+    db = DeviceBatch(prob, n, want_grad=True)
+    refs = [{k: v.clone() for k, v in db.evaluate(X).items()} for X in (X1, X2)]
+    torch.cuda.synchronize()
+    Xin = X1.clone()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        out = db.evaluate(Xin)
+    for X, ref in ((X1, refs[0]), (X2, refs[1]), (X1, refs[0])):
+        Xin.copy_(X)
+        db.cost_minc.zero_()
+        db.grad.zero_()
+        graph.replay()
+        torch.cuda.synchronize()
+        for key in ("cost", "min_clear", "flags", "grad"):
+            assert torch.equal(out[key], ref[key]), key
+    after = db.evaluate(X2)      # back on the ordinary stream
+    torch.cuda.synchronize()
+    assert torch.equal(after["cost"], refs[1]["cost"])
+    db.close()
+
+
 def test_error_paths(native):
     ctx = native.Context(0)
     prob = H.problem_for_case(CASES[0])
