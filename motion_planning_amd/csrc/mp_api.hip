@@ -38,7 +38,7 @@ struct mp_ctx {
     size_t max_lds = 65536;
 
     // scene
-    DevBuf boxes, boxes32, groups;
+    DevBuf boxes, boxes32, pairs32, groups;
     std::vector<double> h_boxes;  // host copy of the scene (n x 6) for the per-task bound tables
     float scene_radius = 0.f;
     int has_rot = 0;              // 0 axis-aligned scene, 1 some boxes have a yaw of their own, 2 some are tilted
@@ -287,13 +287,14 @@ template <typename T> int upload_problem(mp_ctx *ctx, const mp_task *tasks)
     {
         constexpr int kGroup = 16, kGroupMin = 128;
         std::vector<mp::BoxRec32> sb, gr;
-        std::vector<std::array<int, 6>> done;  // begin, count, sbox_begin, group_begin, group_count, n_wide
+        std::vector<mp::BoxPair32> sp;   // the sorted boxes two per record, group by group
+        std::vector<std::array<int, 7>> done;  // begin, count, sbox_begin, group_begin, group_count, n_wide, spair_begin
         std::unordered_map<long long, size_t> done_at;   // (begin, count) -> index in done (10,000-task batches)
         auto as_float = [](int v) { float f; std::memcpy(&f, &v, 4); return f; };
         for (int i = 0; i < ctx->n_tasks; ++i) {
             const int b0 = tasks[i].box_begin;
             int cnt = tasks[i].box_count;
-            const std::array<int, 6> *hit = nullptr;
+            const std::array<int, 7> *hit = nullptr;
             {
                 const auto it = done_at.find(((long long)b0 << 32) | (unsigned int)cnt);
                 if (it != done_at.end()) hit = &done[it->second];
@@ -370,7 +371,7 @@ template <typename T> int upload_problem(mp_ctx *ctx, const mp_task *tasks)
                         order.swap(reordered);
                     }
                 }
-                const int sb0 = (int)sb.size(), g0 = (int)gr.size();
+                const int sb0 = (int)sb.size(), g0 = (int)gr.size(), sp0 = (int)sp.size();
                 const int gsz = cnt >= kGroupMin ? kGroup : std::max(cnt, 1);
                 auto down = [](double v) { float f = (float)v; return (double)f > v ? std::nextafter(f, -INFINITY) : f; };
                 auto up = [](double v) { float f = (float)v; return (double)f < v ? std::nextafter(f, INFINITY) : f; };
@@ -399,6 +400,20 @@ template <typename T> int upload_problem(mp_ctx *ctx, const mp_task *tasks)
                     g.pad0 = as_float(k + n_wide);   // first record of the group, relative to sbox_begin
                     g.pad1 = as_float(m);
                     gr.push_back(g);
+                    // the group's boxes two by two (what the sweep reads); an odd last box shares its record with nobody
+                    for (int q = 0; q < m; q += 2) {
+                        const mp::BoxRec32 &r0 = sb[(size_t)sbr + k + q];
+                        const bool two = q + 1 < m;
+                        const mp::BoxRec32 &r1 = two ? sb[(size_t)sbr + k + q + 1] : r0;
+                        mp::BoxPair32 pr;
+                        pr.lox = mp::v2f{r0.lox, r1.lox}; pr.loy = mp::v2f{r0.loy, r1.loy}; pr.loz = mp::v2f{r0.loz, r1.loz};
+                        pr.hix = mp::v2f{r0.hix, r1.hix}; pr.hiy = mp::v2f{r0.hiy, r1.hiy}; pr.hiz = mp::v2f{r0.hiz, r1.hiz};
+                        std::memcpy(&pr.idx0, &r0.pad0, 4);
+                        pr.idx1 = -1;
+                        if (two) std::memcpy(&pr.idx1, &r1.pad0, 4);
+                        pr.pad0 = 0.f; pr.pad1 = 0.f;
+                        sp.push_back(pr);
+                    }
                     // representative: the member whose centre is nearest to the centre of the group's AABB
                     const float gcx = 0.5f * (g.lox + g.hix), gcy = 0.5f * (g.loy + g.hiy), gcz = 0.5f * (g.loz + g.hiz);
                     int best = 0;
@@ -412,7 +427,7 @@ template <typename T> int upload_problem(mp_ctx *ctx, const mp_task *tasks)
                     if (m > 0) { rep.lox = centre[(size_t)k + best][0]; rep.loy = centre[(size_t)k + best][1]; rep.loz = centre[(size_t)k + best][2]; }
                     gr.push_back(rep);
                 }
-                done.push_back({b0, cnt_all, sb0, g0 / 2, ((int)gr.size() - g0) / 2, n_wide});
+                done.push_back({b0, cnt_all, sb0, g0 / 2, ((int)gr.size() - g0) / 2, n_wide, sp0});
                 done_at[((long long)b0 << 32) | (unsigned int)cnt_all] = done.size() - 1;
                 hit = &done.back();
             }
@@ -420,9 +435,11 @@ template <typename T> int upload_problem(mp_ctx *ctx, const mp_task *tasks)
             dt[i].group_begin = (*hit)[3];
             dt[i].group_count = (*hit)[4];
             dt[i].n_wide = (*hit)[5];
+            dt[i].spair_begin = (*hit)[6];
         }
         if ((rc = upload(ctx, ctx->boxes32, sb.data(), sb.size() * sizeof(mp::BoxRec32)))) return rc;
         if ((rc = upload(ctx, ctx->groups, gr.data(), gr.size() * sizeof(mp::BoxRec32)))) return rc;
+        if ((rc = upload(ctx, ctx->pairs32, sp.data(), sp.size() * sizeof(mp::BoxPair32)))) return rc;
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     }
     if ((rc = upload(ctx, ctx->d_tasks, dt.data(), dt.size() * sizeof(mp::DevTask<T>)))) return rc;
@@ -477,7 +494,7 @@ int launch_eval(mp_ctx *ctx, long long n, const void *X, const int32_t *task_of,
     a.idx_safe = (const int *)ctx->d_idx.p; a.idx_identity = ctx->idx_identity; a.amask = (const uint8_t *)ctx->d_mask.p;
     a.M = (const T *)ctx->d_M.p; a.My = (const T *)ctx->d_My.p; a.tsched = (const T *)ctx->d_tsched.p;
     a.tasks = (const mp::DevTask<T> *)ctx->d_tasks.p; a.boxes = (const mp::BoxRec<T> *)ctx->boxes.p;
-    a.boxes32 = (const mp::BoxRec32 *)ctx->boxes32.p; a.groups = (const mp::BoxRec32 *)ctx->groups.p;
+    a.boxes32 = (const mp::BoxRec32 *)ctx->boxes32.p; a.pairs = (const mp::BoxPair32 *)ctx->pairs32.p; a.groups = (const mp::BoxRec32 *)ctx->groups.p;
     a.scene_radius = ctx->scene_radius;
     a.tilt = (const T *)ctx->tilt.p;
     a.X = (const T *)X; a.task_of = task_of; a.cpt = ctx->cands_per_task; a.n = n;
@@ -705,7 +722,7 @@ int mp_destroy(mp_ctx *ctx)
     if (!ctx) return MP_OK;
     hipSetDevice(ctx->device);
     hipStreamSynchronize(ctx->stream);
-    DevBuf *bufs[] = {&ctx->boxes, &ctx->boxes32, &ctx->groups, &ctx->d_idx, &ctx->d_mask, &ctx->d_M, &ctx->d_My, &ctx->d_tsched, &ctx->d_tasks,
+    DevBuf *bufs[] = {&ctx->boxes, &ctx->boxes32, &ctx->pairs32, &ctx->groups, &ctx->d_idx, &ctx->d_mask, &ctx->d_M, &ctx->d_My, &ctx->d_tsched, &ctx->d_tasks,
                       &ctx->s_X, &ctx->s_taskof, &ctx->s_cost, &ctx->s_terms, &ctx->s_grad, &ctx->s_minc,
                       &ctx->s_flags, &ctx->s_dist, &ctx->s_aux0, &ctx->s_aux1, &ctx->s_pre_d, &ctx->s_pre_arg, &ctx->tilt, &ctx->c_X, &ctx->c_vals, &ctx->c_minc,
                       &ctx->c_flags, &ctx->c_mu, &ctx->c_sigma, &ctx->c_bestx, &ctx->c_bestval, &ctx->c_prev, &ctx->c_bminc,

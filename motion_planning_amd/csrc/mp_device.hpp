@@ -520,6 +520,34 @@ __device__ __forceinline__ float aabb_lb2(float mlox, float mloy, float mloz, fl
     return __builtin_fmaf(mz, mz, __builtin_fmaf(my, my, mx * mx));
 }
 
+// Two consecutive boxes of the sorted bound table side by side, so that the bound pass tests them with packed fp32
+// instructions (v_pk_add_f32 / v_pk_mul_f32 / v_pk_fma_f32: two boxes per instruction, only the max3 and the compare
+// stay per box): 17 VALU per pair instead of 13 per box.  idx1 < 0: the pair holds one box only (odd group size).
+typedef float v2f __attribute__((ext_vector_type(2)));
+struct BoxPair32 { v2f lox, loy, loz, hix, hiy, hiz; int idx0, idx1; float pad0, pad1; };
+
+__device__ __forceinline__ BoxPair32 load_pair_uniform(const BoxPair32 *pairs, int i)
+{
+    typedef const float __attribute__((address_space(4))) *CPtr;
+    CPtr p = (CPtr)(unsigned long long)(pairs + i);
+    BoxPair32 r;
+    r.lox = v2f{p[0], p[1]}; r.loy = v2f{p[2], p[3]}; r.loz = v2f{p[4], p[5]};
+    r.hix = v2f{p[6], p[7]}; r.hiy = v2f{p[8], p[9]}; r.hiz = v2f{p[10], p[11]};
+    r.idx0 = __float_as_int(p[12]); r.idx1 = __float_as_int(p[13]);
+    r.pad0 = 0.f; r.pad1 = 0.f;
+    return r;
+}
+
+// aabb_lb2 for both boxes of a pair (same operations per component)
+__device__ __forceinline__ v2f aabb_lb2_pair(float mlox, float mloy, float mloz, float mhix, float mhiy, float mhiz, const BoxPair32 &b)
+{
+    const v2f ax = b.lox - mhix, bx = mlox - b.hix, ay = b.loy - mhiy, by = mloy - b.hiy, az = b.loz - mhiz, bz = mloz - b.hiz;
+    const v2f mx = v2f{__builtin_fmaxf(__builtin_fmaxf(ax.x, bx.x), 0.f), __builtin_fmaxf(__builtin_fmaxf(ax.y, bx.y), 0.f)};
+    const v2f my = v2f{__builtin_fmaxf(__builtin_fmaxf(ay.x, by.x), 0.f), __builtin_fmaxf(__builtin_fmaxf(ay.y, by.y), 0.f)};
+    const v2f mz = v2f{__builtin_fmaxf(__builtin_fmaxf(az.x, bz.x), 0.f), __builtin_fmaxf(__builtin_fmaxf(az.y, bz.y), 0.f)};
+    return __builtin_elementwise_fma(mz, mz, __builtin_elementwise_fma(my, my, mx * mx));
+}
+
 // d(pair)/d(px,py,pz,theta[rad]) for the deciding box (mirrors the oracle's pair_grad)
 template <typename T>
 __device__ __forceinline__ void pair_grad_local(const Pose<T> &p, T ax, T ay, T az, T bcx, T bcy, const BoxRec<T> bx,

@@ -44,6 +44,7 @@ template <typename T> struct DevTask {
     T normal[3];
     int has_normal, yaw_inc, box_begin, box_count;
     int sbox_begin;    // first record of this task's spatially sorted fp32 table (sboxes32)
+    int spair_begin;   // first record of the same boxes (without the wide one) in the pair table, group by group
     int group_begin;   // first group of this task in the group table (records 2*group_begin ...)
     int group_count;   // groups of kGroupSize consecutive sorted boxes (1 group: no group test)
     int n_wide;        // 1: record 0 of the sorted table is a wide box handled before the sweep (clearance_chunk)
@@ -66,6 +67,7 @@ template <typename T> struct EvalArgs {
     const BoxRec<T> *boxes;
     const T *tilt;            // rotation matrices (9 values each) of the tilted boxes, indexed by their cb field; or NULL
     const BoxRec32 *boxes32;  // fp32 bound-pass table, sorted along a Morton curve per task; pad0 = original index
+    const BoxPair32 *pairs;   // the sorted boxes again, two per record (what the sweep reads)
     const BoxRec32 *groups;   // per group of consecutive sorted boxes two records: [2g] AABB, pad0/pad1 = first / count;
                               // [2g+1] centre of a representative box of the group
     float scene_radius;       // max |centre| + half extent over the scene (slack of the bound)
@@ -144,7 +146,7 @@ __host__ __device__ inline int lds_bytes_per_wave(int S, int e, bool grad)
 // kernel, which serves every scene large enough to have groups).  On return MINKEY[slot] holds the ordered key of the scene value, ARG[slot] the deciding box
 // (-1: none) and CC/SS the (cos, sin) of the sample's yaw.
 template <typename T, int ROT, bool LOCAL, bool SEED>
-__device__ __forceinline__ void clearance_chunk(const EvalArgs<T> &a, const BoxRec<T> *boxes, const BoxRec32 *boxes32,
+__device__ __forceinline__ void clearance_chunk(const EvalArgs<T> &a, const BoxRec<T> *boxes, const BoxRec32 *boxes32, const BoxPair32 *pairs,
                                                 const BoxRec32 *groups, int ngroups, int n_wide, int lane, int k0, int Sp, const T *P0,
                                                 const T *P1, const T *P2, const T *YW, T *CC, T *SS,
                                                 unsigned long long *MINKEY, int *ARG, unsigned int *QUEUE)
@@ -280,17 +282,14 @@ __device__ __forceinline__ void clearance_chunk(const EvalArgs<T> &a, const BoxR
             if (!__builtin_amdgcn_ballot_w64(lbg <= U32)) continue;
         }
         MP_STAT_ADD(1, 1); MP_STAT_ADD(2, gcnt);
-        BoxRec32 nxt = load_box32_uniform(boxes32, gfirst);
-        for (int i = 0; i < gcnt; ++i) {
-            const BoxRec32 bx = nxt;
-            nxt = load_box32_uniform(boxes32, gfirst + (i + 1 < gcnt ? i + 1 : i));
-            const float lb2 = aabb_lb2(mlox, mloy, mloz, mhix, mhiy, mhiz, bx);
-            const bool need = lb2 <= U32;
+        // two boxes per trip (packed fp32): group j of 16 records is pairs 8j ... of the task's pair table
+        const int pfirst = (gfirst - n_wide) >> 1, npairs = (gcnt + 1) >> 1;
+        auto push = [&](bool need, int idx) {
             const unsigned long long m = __builtin_amdgcn_ballot_w64(need);
             if (m) {
                 if (need) {
                     const int pos = __builtin_amdgcn_mbcnt_hi((unsigned int)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)m, 0u));
-                    QUEUE[(qhead + qcount + pos) & 127] = ((unsigned int)lane << 24) | (unsigned int)__float_as_int(bx.pad0);
+                    QUEUE[(qhead + qcount + pos) & 127] = ((unsigned int)lane << 24) | (unsigned int)idx;
                 }
                 qcount += __builtin_popcountll(m);
                 if (qcount >= 64) {
@@ -299,6 +298,14 @@ __device__ __forceinline__ void clearance_chunk(const EvalArgs<T> &a, const BoxR
                     qcount -= 64;
                 }
             }
+        };
+        BoxPair32 nxt = load_pair_uniform(pairs, pfirst);
+        for (int i = 0; i < npairs; ++i) {
+            const BoxPair32 bp = nxt;
+            nxt = load_pair_uniform(pairs, pfirst + (i + 1 < npairs ? i + 1 : i));
+            const v2f lb2 = aabb_lb2_pair(mlox, mloy, mloz, mhix, mhiy, mhiz, bp);
+            push(lb2.x <= U32, bp.idx0);
+            push(bp.idx1 >= 0 && lb2.y <= U32, bp.idx1);   // against the bound as the first push may have refreshed it
         }
     }
     if (qcount > 0) drain(qcount);
@@ -488,7 +495,7 @@ __global__ void __launch_bounds__(256, (eval_min_waves<T, GRAD, ROT>())) eval_ke
             const int ngroups = __builtin_amdgcn_readfirstlane(tk.group_count);
             const int n_wide = __builtin_amdgcn_readfirstlane(tk.n_wide);
             for (int k0 = 0; k0 < Sp; k0 += 64) {
-                clearance_chunk<T, ROT, false, false>(a, boxes, boxes32, groups, ngroups, n_wide, lane, k0, Sp, P0, P1, P2, YW, CC + k0, SS + k0,
+                clearance_chunk<T, ROT, false, false>(a, boxes, boxes32, a.pairs + __builtin_amdgcn_readfirstlane(tk.spair_begin), groups, ngroups, n_wide, lane, k0, Sp, P0, P1, P2, YW, CC + k0, SS + k0,
                                                MINKEY + k0, ARG + k0, QUEUE);
                 const int k = k0 + lane;
                 if (k < Sp) {
@@ -883,7 +890,7 @@ __global__ void __launch_bounds__(256) clearance_kernel(const EvalArgs<T> a)
             P0[lane] = px; P1[lane] = py; P2[lane] = pz; YW[lane] = yw;
         }
         wave_lds_sync();
-        clearance_chunk<T, ROT, true, true>(a, boxes, boxes32, groups, ngroups, n_wide, lane, k0, a.Sp, P0, P1, P2, YW, CC, SS, MINKEY, ARG, QUEUE);
+        clearance_chunk<T, ROT, true, true>(a, boxes, boxes32, a.pairs + __builtin_amdgcn_readfirstlane(tk.spair_begin), groups, ngroups, n_wide, lane, k0, a.Sp, P0, P1, P2, YW, CC, SS, MINKEY, ARG, QUEUE);
         if (k < a.Sp) {
             a.pre_d[cand * a.Sp + k] = key_to_distance<T>(MINKEY[lane]);
             a.pre_arg[cand * a.Sp + k] = ARG[lane];
