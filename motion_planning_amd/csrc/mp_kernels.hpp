@@ -66,7 +66,8 @@ template <typename T> struct EvalArgs {
     const DevTask<T> *tasks;
     const BoxRec<T> *boxes;
     const T *tilt;            // rotation matrices (9 values each) of the tilted boxes, indexed by their cb field; or NULL
-    const BoxRec32 *boxes32;  // fp32 bound-pass table, sorted along a Morton curve per task; pad0 = original index
+    const BoxRec32 *boxes32;  // fp32 bound table, one record per box, sorted along a Morton curve per task; pad0 = original
+                              // index (the kernels read the wide box, record 0, from it; the host builds pairs and groups from it)
     const BoxPair32 *pairs;   // the sorted boxes again, two per record (what the sweep reads)
     const BoxRec32 *groups;   // per group of consecutive sorted boxes two records: [2g] AABB, pad0/pad1 = first / count;
                               // [2g+1] centre of a representative box of the group
