@@ -12,9 +12,12 @@ for N in (16384, 65536, 262144, 1048576):
         db = DeviceBatch(prob, N, want_grad=grad)
         db.evaluate(X)
         db.ctx.set_stream(torch.cuda.current_stream().cuda_stream)
-        db.ctx.timer_start()
-        for _ in range(5):
+        reps = max(5, int(150e6 / N))      # >= 0.1 s of work per measurement, after as much warm-up (clocks settle)
+        for _ in range(reps):
             db.evaluate(X)
-        ms = db.ctx.timer_stop() / 5
+        db.ctx.timer_start()
+        for _ in range(reps):
+            db.evaluate(X)
+        ms = db.ctx.timer_stop() / reps
         print(f"N={N:8d} grad={grad!s:5}: {ms:8.3f} ms  {N / ms * 1e3:.3e} evals/s", flush=True)
         db.close()

@@ -21,9 +21,12 @@ for B, S, N in shapes:
         db = DeviceBatch(prob, N, want_grad=grad)
         db.evaluate(X)
         db.ctx.set_stream(torch.cuda.current_stream().cuda_stream)
-        db.ctx.timer_start()
-        for _ in range(5):
+        reps = int(__import__("os").environ.get("MP_SHAPE_REPS", "5"))   # 5: quick A/B; 100+: settled clocks (absolute figures)
+        for _ in range(reps if reps > 5 else 0):
             db.evaluate(X)
-        ms = db.ctx.timer_stop() / 5
+        db.ctx.timer_start()
+        for _ in range(reps):
+            db.evaluate(X)
+        ms = db.ctx.timer_stop() / reps
         print(f"B={B:5d} S={S:4d} N={N:6d} grad={grad!s:5}: {ms:8.3f} ms  {N / ms * 1e3:.3e} evals/s", flush=True)
         db.close()

@@ -9,7 +9,7 @@ from motion_planning_amd import _native
 from motion_planning_amd.batch import DeviceBatch
 from motion_planning_amd.synthetic import synthetic_candidates, synthetic_problem
 
-N, STEPS = 65536, 40
+N, STEPS = 65536, 200
 prob = synthetic_problem(_native.build_basis, 50, 64, seed=0)
 X = torch.from_numpy(synthetic_candidates(prob, N, seed=5)).cuda()
 for grad in (True, False):
