@@ -2,7 +2,7 @@
 import sys, time
 from pathlib import Path
 import numpy as np
-sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
+sys.path.insert(0, str(Path(__file__).resolve().parents[2]))
 from motion_planning_amd import _native
 from motion_planning_amd.blocks import Block
 from motion_planning_amd.configs import BASE_CONFIG

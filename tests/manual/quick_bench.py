@@ -2,7 +2,7 @@
 import sys
 from pathlib import Path
 import numpy as np
-sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
+sys.path.insert(0, str(Path(__file__).resolve().parents[2]))
 import torch
 from motion_planning_amd import _native
 from motion_planning_amd.batch import DeviceBatch
