@@ -110,7 +110,10 @@ def main():
     if os.environ.get("MP_BENCH_ONE_DEVICE") == "1":
         local_rank = 0
     backend = os.environ.get("MP_BENCH_BACKEND", "nccl")
-    if world > 1:
+    # MP_BENCH_FORCE_DIST=1 under torchrun with ONE rank drives the whole collective path (RCCL communicator, async gathers,
+    # barrier) on a one-GPU box
+    distributed = world > 1 or os.environ.get("MP_BENCH_FORCE_DIST") == "1"
+    if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
         if backend == "nccl":
@@ -128,32 +131,29 @@ def main():
     Xh = synthetic_candidates(problem, N_CAND, seed=100 + rank, dtype=np_dtype)   # this rank's index shard
     X = torch.from_numpy(Xh).cuda()
     # two output slots: the collectives of step i read slot i % 2 while step i + 1 computes into the other one
-    dbs = [DeviceBatch(problem, N_CAND, device=local_rank, dtype=np_dtype, want_grad=True) for _ in range(2 if world > 1 else 1)]
+    dbs = [DeviceBatch(problem, N_CAND, device=local_rank, dtype=np_dtype, want_grad=True) for _ in range(2 if distributed else 1)]
     db = dbs[0]
     # collectives run on device tensors over RCCL; the gloo rehearsal (one-GPU box) stages them through the host
     coll_dev = "cuda" if backend == "nccl" else "cpu"
-    if world > 1:
-        gather_val = [torch.empty(world * 2, N_CAND, dtype=tdtype, device=coll_dev) for _ in range(2)]
-        gather_flg = [torch.empty(world * N_CAND, dtype=torch.uint8, device=coll_dev) for _ in range(2)]
+    if distributed:
+        gather_buf = [torch.empty(world * db.results_bytes.numel(), dtype=torch.uint8, device=coll_dev) for _ in range(2)]
 
     def step(i, pending):
         cur = dbs[i % len(dbs)]
-        if world > 1 and len(pending) >= 2:
+        if distributed and len(pending) >= 2:
             for w in pending.pop(0):   # the collectives that read this slot two steps ago
                 w.wait()
         out = cur.evaluate(X)
-        if world > 1:
-            # the kernel's own output buffers go into the collectives (cost and min clearance are one tensor): no
-            # packing kernel; the gathers run on RCCL's stream while the next step computes into the other slot
-            val = cur.cost_minc if coll_dev == "cuda" else cur.cost_minc.cpu()
-            flg = cur.flags if coll_dev == "cuda" else cur.flags.cpu()
-            pending.append((dist.all_gather_into_tensor(gather_val[i % 2], val, async_op=True),
-                            dist.all_gather_into_tensor(gather_flg[i % 2], flg, async_op=True)))
+        if distributed:
+            # the kernel's own output buffer goes into the collective (cost, min clearance and flags share one allocation):
+            # no packing kernel, one gather per step on RCCL's stream while the next step computes into the other slot
+            res = cur.results_bytes if coll_dev == "cuda" else cur.results_bytes.cpu()
+            pending.append((dist.all_gather_into_tensor(gather_buf[i % 2], res, async_op=True),))
         return out
 
     def sync():
         torch.cuda.synchronize()
-        if world > 1:
+        if distributed:
             dist.barrier()
             torch.cuda.synchronize()
 
@@ -178,7 +178,7 @@ def main():
             w.wait()
     sync()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if distributed:
         t = torch.tensor([elapsed], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -267,7 +267,7 @@ def main():
         cnt = torch.tensor([float(res["solved"].sum()), float(n_sc)], dtype=torch.float64, device=coll_dev)
         sync()
         el5 = time.perf_counter() - t1
-        if world > 1:
+        if distributed:
             dist.all_reduce(cnt)
             t5 = torch.tensor([el5], dtype=torch.float64, device=coll_dev)
             dist.all_reduce(t5, op=dist.ReduceOp.MAX)
@@ -314,7 +314,7 @@ def main():
         print(json.dumps(line))
     for d in dbs:
         d.close()
-    if world > 1:
+    if distributed:
         dist.barrier()   # rank 0 prints and times the CPU baseline last; nobody tears the group down early
         dist.destroy_process_group()
 

@@ -54,10 +54,14 @@ class DeviceBatch:
         D = self.problem.dim
         # cost and min clearance are the two rows of one buffer, so that a job can all-gather both with one collective
         # straight from the kernel's output (no packing kernel in between)
-        self.cost_minc = torch.empty(2, capacity, dtype=self.tdtype, device=dev)
+        # ... and the flags follow in the same allocation: `results_bytes` (cost | min clearance | flags as raw bytes) is
+        # what a job hands to ONE all-gather per step
+        es = self.np_dtype.itemsize
+        self.results_bytes = torch.empty((2 * es + 1) * capacity, dtype=torch.uint8, device=dev)
+        self.cost_minc = self.results_bytes[:2 * es * capacity].view(self.tdtype).view(2, capacity)
         self.cost = self.cost_minc[0]
         self.min_clear = self.cost_minc[1]
-        self.flags = torch.empty(capacity, dtype=torch.uint8, device=dev)
+        self.flags = self.results_bytes[2 * es * capacity:]
         self.grad = torch.empty(capacity, D, dtype=self.tdtype, device=dev) if want_grad else None
         self.terms = torch.empty(capacity, abi.MP_NTERMS, dtype=self.tdtype, device=dev) if want_terms else None
 
