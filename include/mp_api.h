@@ -14,6 +14,8 @@
  *
  * Threading: a context is NOT re-entrant (callers serialise calls on one context);
  * different contexts are independent.  One context per GPU per process.
+ * Current device: every entry point makes the context's GPU current for the duration
+ * of the call and puts the caller's current HIP device back before it returns.
  */
 #ifndef MP_API_H
 #define MP_API_H
@@ -202,7 +204,10 @@ int mp_get_basis(mp_ctx *ctx, double *M /* [S x C] */, double *M_yaw /* [S x Cy]
  *   X         [n x D]      candidates, row-major, element type = context dtype
  *   task_of   [n] or NULL  task index per candidate; NULL: candidate i belongs to
  *                          task (i / cands_per_task) — see mp_set_cands_per_task —
- *                          (default: everything is task 0)
+ *                          (default: everything is task 0).  Host arrays are range-
+ *                          checked (MP_E_ARG); a device array cannot be, so a candidate
+ *                          whose entry lies outside [0, n_tasks) gets NaN cost / terms /
+ *                          grad / min_clear and flags 0, and no table is read for it
  *   cost      [n]          weighted total j                         (required)
  *   terms     [n x 15]     unweighted terms, mp_term order          (or NULL)
  *   grad      [n x D]      d cost / d x (analytic sub-gradient)     (or NULL)

@@ -69,8 +69,16 @@ class DeviceBatch:
         n = X.shape[0]
         if n > self.capacity:
             raise ValueError("batch larger than the preallocated capacity")
-        if X.dtype != self.tdtype or not X.is_cuda or not X.is_contiguous() or X.shape[1] != self.problem.dim:
+        if X.dtype != self.tdtype or not X.is_cuda or not X.is_contiguous() or X.ndim != 2 or X.shape[1] != self.problem.dim:
             raise ValueError("X must be a contiguous CUDA tensor of the context dtype with D columns")
+        if X.device.index != self.device:
+            raise ValueError(f"X lives on cuda:{X.device.index}, this batch on cuda:{self.device}")
+        if task_of is not None:
+            # the library reads task_of as int32 device memory and does not range-check it on the host (out-of-range
+            # entries come back as NaN cost / flags 0 from the kernel); torch's default index dtype is int64
+            if (task_of.dtype != torch.int32 or not task_of.is_cuda or task_of.device.index != self.device
+                    or not task_of.is_contiguous() or task_of.ndim != 1 or task_of.numel() < n):
+                raise ValueError("task_of must be a contiguous 1-D int32 CUDA tensor on this batch's device with at least n entries")
         stream = torch.cuda.current_stream(self.device).cuda_stream
         if stream != self._stream:
             self.ctx.set_stream(stream)

@@ -5,6 +5,7 @@
 
 #include <algorithm>
 #include <array>
+#include <atomic>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -90,6 +91,13 @@ int fail(mp_ctx *ctx, int code, const char *fmt, ...)
 int reserve(mp_ctx *ctx, DevBuf &b, size_t bytes)
 {
     if (bytes <= b.cap && b.p) return MP_OK;
+    {   // growing a buffer while the caller's stream is being captured into a graph would invalidate the capture
+        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+        if (ctx->stream && hipStreamIsCapturing(ctx->stream, &cap) != hipSuccess) { (void)hipGetLastError(); cap = hipStreamCaptureStatusNone; }
+        if (cap != hipStreamCaptureStatusNone)
+            return fail(ctx, MP_E_STATE, "a device buffer would have to grow to %zu bytes while the stream is being captured: "
+                        "make one ordinary call of this shape before capturing", bytes);
+    }
     if (b.p) HIP_TRY(ctx, hipFree(b.p));
     b.p = nullptr;
     b.cap = 0;
@@ -451,9 +459,16 @@ template <typename T, int MODEL, bool GRAD, int ROT, bool PRE>
 int launch_eval_p(mp_ctx *ctx, const mp::EvalArgs<T> &args, int wpb, int blocks, size_t lds_bytes)
 {
     auto kern = mp::eval_kernel<T, MODEL, GRAD, ROT, PRE>;
-    if (lds_bytes > 65536)
-        HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                         (int)lds_bytes));
+    if (lds_bytes > 65536) {
+        // the opt-in for > 64 KB of dynamic LDS is per kernel variant and device: set once, raise when a larger slice comes
+        static std::atomic<int> granted[64];
+        std::atomic<int> &g = granted[ctx->device & 63];
+        if ((int)lds_bytes > g.load(std::memory_order_relaxed)) {
+            HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                             (int)lds_bytes));
+            g.store((int)lds_bytes, std::memory_order_relaxed);
+        }
+    }
     hipLaunchKernelGGL(kern, dim3(blocks), dim3(64 * wpb), lds_bytes, ctx->stream, args);
     HIP_TRY(ctx, hipGetLastError());
     return MP_OK;
@@ -666,13 +681,26 @@ int cem_solve(mp_ctx *ctx, long long n_inst, const int32_t *d_task, const T *d_x
     return MP_OK;
 }
 
-int check_ctx(mp_ctx *ctx)
-{
-    if (!ctx) return MP_E_ARG;
-    hipError_t e = hipSetDevice(ctx->device);
-    if (e != hipSuccess) return fail(ctx, MP_E_HIP, "hipSetDevice(%d): %s", ctx->device, hipGetErrorString(e));
-    return MP_OK;
-}
+// Every entry point runs with the context's GPU current and puts the caller's device back on return (a context on
+// cuda:1 must not move a thread whose torch device is cuda:0).
+struct DeviceGuard {
+    int prev = -1;
+    int enter(mp_ctx *ctx)
+    {
+        if (!ctx) return MP_E_ARG;
+        int cur = -1;
+        if (hipGetDevice(&cur) != hipSuccess) { (void)hipGetLastError(); cur = -1; }
+        if (cur == ctx->device) return MP_OK;
+        hipError_t e = hipSetDevice(ctx->device);
+        if (e != hipSuccess) return fail(ctx, MP_E_HIP, "hipSetDevice(%d): %s", ctx->device, hipGetErrorString(e));
+        prev = cur;
+        return MP_OK;
+    }
+    ~DeviceGuard()
+    {
+        if (prev >= 0) (void)hipSetDevice(prev);
+    }
+};
 
 }  // namespace
 
@@ -694,6 +722,11 @@ int mp_create(int device_id, int dtype, mp_ctx **out)
                     e != hipSuccess ? hipGetErrorString(e) : "device count is 0");
     if (device_id < 0 || device_id >= count)
         return fail(nullptr, MP_E_ARG, "mp_create: device_id %d out of range (0..%d)", device_id, count - 1);
+    struct Restore {   // mp_create leaves the caller's current device as it found it
+        int prev = -1;
+        Restore() { if (hipGetDevice(&prev) != hipSuccess) { (void)hipGetLastError(); prev = -1; } }
+        ~Restore() { if (prev >= 0) (void)hipSetDevice(prev); }
+    } restore_;
     mp_ctx *ctx = new mp_ctx();
     ctx->device = device_id;
     if (const char *sm = std::getenv("MP_SPLIT_CLEARANCE")) ctx->split_mode = std::atoi(sm) != 0 ? 1 : 0;
@@ -720,7 +753,8 @@ int mp_create(int device_id, int dtype, mp_ctx **out)
 int mp_destroy(mp_ctx *ctx)
 {
     if (!ctx) return MP_OK;
-    hipSetDevice(ctx->device);
+    DeviceGuard guard_;
+    (void)guard_.enter(ctx);
     hipStreamSynchronize(ctx->stream);
     DevBuf *bufs[] = {&ctx->boxes, &ctx->boxes32, &ctx->pairs32, &ctx->groups, &ctx->d_idx, &ctx->d_mask, &ctx->d_M, &ctx->d_My, &ctx->d_tsched, &ctx->d_tasks,
                       &ctx->s_X, &ctx->s_taskof, &ctx->s_cost, &ctx->s_terms, &ctx->s_grad, &ctx->s_minc,
@@ -740,7 +774,8 @@ int mp_destroy(mp_ctx *ctx)
 
 int mp_set_stream(mp_ctx *ctx, void *hip_stream)
 {
-    int rc = check_ctx(ctx);
+    DeviceGuard guard_;
+    int rc = guard_.enter(ctx);
     if (rc) return rc;
     hipStream_t next = (hipStream_t)hip_stream;
     if (next == ctx->stream) return MP_OK;
@@ -756,7 +791,8 @@ int mp_set_stream(mp_ctx *ctx, void *hip_stream)
 
 int mp_use_own_stream(mp_ctx *ctx)
 {
-    int rc = check_ctx(ctx);
+    DeviceGuard guard_;
+    int rc = guard_.enter(ctx);
     if (rc) return rc;
     if (ctx->stream == ctx->own_stream) return MP_OK;
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
@@ -766,7 +802,8 @@ int mp_use_own_stream(mp_ctx *ctx)
 
 int mp_synchronize(mp_ctx *ctx)
 {
-    int rc = check_ctx(ctx);
+    DeviceGuard guard_;
+    int rc = guard_.enter(ctx);
     if (rc) return rc;
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return MP_OK;
@@ -774,7 +811,8 @@ int mp_synchronize(mp_ctx *ctx)
 
 int mp_timer_start(mp_ctx *ctx)
 {
-    int rc = check_ctx(ctx);
+    DeviceGuard guard_;
+    int rc = guard_.enter(ctx);
     if (rc) return rc;
     HIP_TRY(ctx, hipEventRecord(ctx->ev0, ctx->stream));
     return MP_OK;
@@ -782,7 +820,8 @@ int mp_timer_start(mp_ctx *ctx)
 
 int mp_timer_stop(mp_ctx *ctx, float *elapsed_ms)
 {
-    int rc = check_ctx(ctx);
+    DeviceGuard guard_;
+    int rc = guard_.enter(ctx);
     if (rc) return rc;
     if (!elapsed_ms) return fail(ctx, MP_E_ARG, "mp_timer_stop: elapsed_ms is NULL");
     HIP_TRY(ctx, hipEventRecord(ctx->ev1, ctx->stream));
@@ -794,7 +833,8 @@ int mp_timer_stop(mp_ctx *ctx, float *elapsed_ms)
 int mp_set_scene(mp_ctx *ctx, int32_t n_boxes, const double *cx, const double *cy, const double *cz, const double *hx,
                  const double *hy, const double *hz, const double *quat_xyzw)
 {
-    int rc = check_ctx(ctx);
+    DeviceGuard guard_;
+    int rc = guard_.enter(ctx);
     if (rc) return rc;
     if (n_boxes < 0) return fail(ctx, MP_E_ARG, "mp_set_scene: n_boxes < 0");
     if (n_boxes > 0 && (!cx || !cy || !cz || !hx || !hy || !hz)) return fail(ctx, MP_E_ARG, "mp_set_scene: NULL array");
@@ -842,7 +882,8 @@ int mp_build_basis(int32_t n_ctrl, int32_t degree, int32_t n_samples, double *M)
 
 int mp_set_problem(mp_ctx *ctx, const mp_config *cfg, int32_t n_tasks, const mp_task *tasks)
 {
-    int rc = check_ctx(ctx);
+    DeviceGuard guard_;
+    int rc = guard_.enter(ctx);
     if (rc) return rc;
     if (!cfg || !tasks || n_tasks < 1) return fail(ctx, MP_E_ARG, "mp_set_problem: NULL cfg/tasks or n_tasks < 1");
     if (!ctx->have_scene) return fail(ctx, MP_E_STATE, "mp_set_problem: call mp_set_scene first");
@@ -915,7 +956,8 @@ int mp_set_cands_per_task(mp_ctx *ctx, int64_t cands_per_task)
 int mp_eval(mp_ctx *ctx, int64_t n, const void *X, const int32_t *task_of, void *cost, void *terms, void *grad,
             void *min_clear, uint8_t *flags, void *dist, int mem)
 {
-    int rc = check_ctx(ctx);
+    DeviceGuard guard_;
+    int rc = guard_.enter(ctx);
     if (rc) return rc;
     if (!ctx->have_problem) return fail(ctx, MP_E_STATE, "mp_eval: call mp_set_scene and mp_set_problem first");
     if (n < 0 || (n > 0 && (!X || !cost))) return fail(ctx, MP_E_ARG, "mp_eval: X and cost are required");
@@ -1013,8 +1055,6 @@ int mp_eval(mp_ctx *ctx, int64_t n, const void *X, const int32_t *task_of, void 
 
 static int sdf_common(mp_ctx *ctx, int64_t n, int32_t box_begin, int32_t box_count, int mem, const char *who)
 {
-    int rc = check_ctx(ctx);
-    if (rc) return rc;
     if (!ctx->have_scene) return fail(ctx, MP_E_STATE, "%s: call mp_set_scene first", who);
     if (n < 0) return fail(ctx, MP_E_ARG, "%s: n < 0", who);
     if (box_begin < 0 || box_count < 0 || box_begin + box_count > ctx->n_boxes)
@@ -1027,8 +1067,10 @@ static int sdf_common(mp_ctx *ctx, int64_t n, int32_t box_begin, int32_t box_cou
 int mp_point_sdf(mp_ctx *ctx, int64_t n, const void *pts, double point_radius, int32_t box_begin, int32_t box_count,
                  void *out, int mem)
 {
-    int rc = sdf_common(ctx, n, box_begin, box_count, mem, "mp_point_sdf");
+    DeviceGuard guard_;
+    int rc = guard_.enter(ctx);
     if (rc) return rc;
+    if ((rc = sdf_common(ctx, n, box_begin, box_count, mem, "mp_point_sdf"))) return rc;
     if (n == 0) return MP_OK;
     if (!pts || !out) return fail(ctx, MP_E_ARG, "mp_point_sdf: NULL pointer");
     const size_t es = esize(ctx);
@@ -1060,8 +1102,10 @@ int mp_point_sdf(mp_ctx *ctx, int64_t n, const void *pts, double point_radius, i
 int mp_box_sdf(mp_ctx *ctx, int64_t n, const void *pos, const void *yaw_deg, const double size[3], int32_t box_begin,
                int32_t box_count, void *out, int mem)
 {
-    int rc = sdf_common(ctx, n, box_begin, box_count, mem, "mp_box_sdf");
+    DeviceGuard guard_;
+    int rc = guard_.enter(ctx);
     if (rc) return rc;
+    if ((rc = sdf_common(ctx, n, box_begin, box_count, mem, "mp_box_sdf"))) return rc;
     if (n == 0) return MP_OK;
     if (!pos || !yaw_deg || !size || !out) return fail(ctx, MP_E_ARG, "mp_box_sdf: NULL pointer");
     const size_t es = esize(ctx);
@@ -1102,7 +1146,8 @@ int mp_cem_solve(mp_ctx *ctx, int64_t n_inst, const int32_t *task_of_inst, const
                  const mp_cem_options *opt, const void *noise, void *best_x, void *best_val, int32_t *nit,
                  void *best_min_clear, uint8_t *best_flags, int mem)
 {
-    int rc = check_ctx(ctx);
+    DeviceGuard guard_;
+    int rc = guard_.enter(ctx);
     if (rc) return rc;
     if (!ctx->have_problem) return fail(ctx, MP_E_STATE, "mp_cem_solve: call mp_set_scene and mp_set_problem first");
     if (n_inst < 0) return fail(ctx, MP_E_ARG, "mp_cem_solve: n_inst < 0");

@@ -365,6 +365,20 @@ __global__ void __launch_bounds__(256, (eval_min_waves<T, GRAD, ROT>())) eval_ke
         } else {
             tl = a.task_of ? (long long)a.task_of[cand] : (a.cpt > 0 ? cand / a.cpt : 0);
         }
+        if (tl < 0 || tl >= (long long)a.n_tasks) {
+            // a task index outside the problem (device-resident task_of is not checked on the host): no table is
+            // touched, the candidate gets NaN results and no flag
+            const T nan = Lim<T>::inf() - Lim<T>::inf();
+            if (lane == 0) {
+                a.cost[cand] = nan;
+                if (a.minc) a.minc[cand] = nan;
+                if (a.flags) a.flags[cand] = 0;
+            }
+            if (a.terms && lane < kNTerms) a.terms[cand * kNTerms + lane] = nan;
+            if (GRAD) for (int o = lane; o < D; o += 64) a.grad[cand * D + o] = nan;
+            if (a.dist) for (int k = lane; k < a.Sp; k += 64) a.dist[cand * a.Sp + k] = nan;
+            continue;
+        }
         const int t = __builtin_amdgcn_readfirstlane((int)tl);
         const DevTask<T> &tk = a.tasks[t];
         const T *x = a.X + cand * D;
@@ -861,6 +875,7 @@ __global__ void __launch_bounds__(256) clearance_kernel(const EvalArgs<T> a)
         } else {
             tl = a.task_of ? (long long)a.task_of[cand] : (a.cpt > 0 ? cand / a.cpt : 0);
         }
+        if (tl < 0 || tl >= (long long)a.n_tasks) continue;   // eval_kernel reports the candidate as NaN
         const int t = __builtin_amdgcn_readfirstlane((int)tl);
         const DevTask<T> &tk = a.tasks[t];
         const T *x = a.X + cand * D;

@@ -39,34 +39,36 @@ class Scene:
         self._ctx_key = None
 
     # ---- ids -------------------------------------------------------------------------
-    def _ensure_object_id(self, object_id: Optional[str]) -> str:
-        if object_id is None:
-            oid = f"obj_{self._auto_id_counter}"
-            self._auto_id_counter += 1
-            return oid
-        if object_id in self._id_to_index:
-            raise ValueError(f"object_id '{object_id}' already exists in scene.")
-        return object_id
+    def _claim_id(self, wanted: Optional[str]) -> str:
+        """The id a new block gets: the caller's (must be unused) or the next automatic ``obj_<k>``."""
+        if wanted is not None:
+            if wanted in self._id_to_index:
+                raise ValueError(f"object_id '{wanted}' already exists in scene.")
+            return wanted
+        self._auto_id_counter += 1
+        return f"obj_{self._auto_id_counter - 1}"
 
-    def _index_from_id(self, id_or_index: IdLike) -> int:
-        if isinstance(id_or_index, int):
-            if not 0 <= id_or_index < len(self.blocks):
-                raise IndexError(f"Block index {id_or_index} out of range.")
-            return id_or_index
-        if id_or_index not in self._id_to_index:
-            raise KeyError(f"object_id '{id_or_index}' not found.")
-        return self._id_to_index[id_or_index]
+    def _resolve(self, ref: IdLike) -> int:
+        """Index of a block given its list index or its object_id."""
+        if isinstance(ref, int):
+            if ref < 0 or ref >= len(self.blocks):
+                raise IndexError(f"Block index {ref} out of range.")
+            return ref
+        try:
+            return self._id_to_index[ref]
+        except KeyError:
+            raise KeyError(f"object_id '{ref}' not found.") from None
 
     def add_block(self, size, position, quat=(0.0, 0.0, 0.0, 1.0), object_id: Optional[str] = None) -> str:
         """Append a block; returns its object_id (geom/scene.py:35-40)."""
-        oid = self._ensure_object_id(object_id)
+        oid = self._claim_id(object_id)
+        self._id_to_index[oid] = len(self.blocks)
         self.blocks.append(Block(size=size, position=position, quat=quat, object_id=oid))
-        self._id_to_index[oid] = len(self.blocks) - 1
         self._ctx_key = None
         return oid
 
     def get_block(self, id_or_index: IdLike) -> Block:
-        return self.blocks[self._index_from_id(id_or_index)]
+        return self.blocks[self._resolve(id_or_index)]
 
     # ---- distance queries (native) -------------------------------------------------------
     def _native(self, ignore_ids: Optional[Sequence[str]] = None):
@@ -132,7 +134,7 @@ class Scene:
     def get_stack_point_on_face(self, base: IdLike, new_size, face: str, gap: float = 0.0,
                                 tangential_offset: Tuple[float, float] = (0.0, 0.0)) -> np.ndarray:
         """Centre of a block of ``new_size`` placed against ``face`` of ``base`` (geom/scene.py:185-245)."""
-        b = self.blocks[self._index_from_id(base)]
+        b = self.blocks[self._resolve(base)]
         R, c, h_base = self._axes_center_half_extents(b)
         h_new = 0.5 * np.asarray(new_size, dtype=float)
         key = face.lower()

@@ -355,10 +355,25 @@ def test_end_to_end_planner_on_gpu(rec):
     res = getattr(so, rec["fn"])(BoxList(H.blocks_from(scen["blocks"])), *rec["args"], **kw)
     info, ref = res[-1], rec["info"]
     vias = np.array(res[1:-1] if rec["fn"].endswith("two_vias") else res[1], dtype=float)
+    rv = np.array(rec["vias"])
+    achieved = {"case": rec["name"], "fun_rel": float(abs(info["fun"] - ref["fun"]) / abs(ref["fun"])),
+                "vias_abs": float(np.abs(vias - rv).max()), "min_clearance_abs": float(abs(info["min_clearance"] - ref["min_clearance"]))}
+    out_dir = H.GOLDEN.parents[1] / "gpurun_out"
+    if out_dir.is_dir():   # keep the achieved errors (DESIGN.md 6 quotes them)
+        with open(out_dir / "g5_achieved_errors.jsonl", "a") as fh:
+            fh.write(json.dumps(achieved) + "\n")
+    # north-star bar: optimised control points and cost within 1e-9 of the reference's own solve.  Measured on MI355X
+    # (round 2, gpurun_out/g5_achieved_errors.jsonl): the seeded CEM and the Nelder-Mead solves reproduce the reference's
+    # vias bit for bit (0.0), `fun` <= 3e-15 relative everywhere; Powell / CEM-POWELL end 6.5e-10 / 5.8e-11 away in the
+    # vias (line searches on a flat minimum amplify the 1e-16 objective difference): bound = 10x measured
     assert info["nit"] == ref["nit"] and info["message"] == ref["message"]
-    assert info["fun"] == pytest.approx(ref["fun"], rel=1e-6)
-    np.testing.assert_allclose(vias, np.array(rec["vias"]), rtol=1e-5, atol=1e-6)
-    assert info["min_clearance"] == pytest.approx(ref["min_clearance"], rel=1e-5, abs=1e-7)
+    assert info["fun"] == pytest.approx(ref["fun"], rel=1e-9), achieved
+    if "powell" in rec["name"] or "hybrid" in rec["name"]:
+        np.testing.assert_allclose(vias, rv, rtol=0, atol=6.5e-9, err_msg=str(achieved))
+        assert info["min_clearance"] == pytest.approx(ref["min_clearance"], rel=1e-9, abs=1.5e-10), achieved
+    else:
+        np.testing.assert_allclose(vias, rv, rtol=1e-9, atol=1e-12, err_msg=str(achieved))
+        assert info["min_clearance"] == pytest.approx(ref["min_clearance"], rel=1e-9, abs=1e-12), achieved
     assert (info["min_clearance"] < 0) == (ref["min_clearance"] < 0)
 
 
@@ -382,7 +397,7 @@ def test_device_cem_follows_the_reference_update(native, oracle_lib):
     assert int(dev["nit"][0]) == host["nit"] == rec["info"]["nit"]
     assert dev["fun"][0] == pytest.approx(host["fun"], rel=1e-9)
     np.testing.assert_allclose(dev["x"][0], host["x"], rtol=1e-9, atol=1e-12)
-    assert dev["fun"][0] == pytest.approx(rec["info"]["fun"], rel=1e-6)
+    assert dev["fun"][0] == pytest.approx(rec["info"]["fun"], rel=1e-9)
     # the recorded flags / clearance belong to the best candidate
     chk = ctx.eval(dev["x"], want_terms=False)
     assert chk["flags"][0] == dev["flags"][0] and chk["min_clear"][0] == dev["min_clear"][0]

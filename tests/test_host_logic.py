@@ -77,23 +77,28 @@ def _kwargs(rec):
 
 @pytest.mark.parametrize("rec", G5, ids=[r["name"] for r in G5])
 def test_end_to_end_solves_match_reference(rec, oracle_lib):
-    """Same optimiser, same seeds; the objective differs from the reference's by ~1e-15 relative
-    (own trig, M @ W sampling), which the derivative-free searches may amplify slightly: compare
-    the outcome at 1e-6 and the bookkeeping exactly."""
+    """Same optimiser, same seeds; the objective differs from the reference's by ~1e-15 relative (own trig,
+    M @ W sampling).  North-star bar: optimised control points and cost within 1e-9 of the reference's solve.
+    Measured (round 2, oracle evaluator): seeded CEM and Nelder-Mead solves reproduce the reference's vias
+    bit for bit (selection by ranking / simplex comparisons never flip), Powell and CEM-POWELL end within
+    7e-12 absolute (Brent line searches amplify the 1e-15 objective difference by ~1e3); `fun` <= 4e-15 relative."""
     fn = getattr(so, rec["fn"])
     res = fn(_scene(rec["scenario"]), *rec["args"], evaluator_factory=oracle_lib.OracleEvaluator, **_kwargs(rec))
     info, ref = res[-1], rec["info"]
     vias = np.array(res[1:-1] if rec["fn"].endswith("two_vias") else res[1], dtype=float)
     assert list(info.keys()) == [k for k in _expected_keys(rec["fn"])]
     assert info["nit"] == ref["nit"] and info["success"] == ref["success"] and info["message"] == ref["message"]
-    assert info["fun"] == pytest.approx(ref["fun"], rel=1e-6)
-    np.testing.assert_allclose(vias, np.array(rec["vias"]), rtol=1e-5, atol=1e-6)
+    assert info["fun"] == pytest.approx(ref["fun"], rel=1e-9)
+    if "powell" in rec["name"] or "hybrid" in rec["name"]:
+        np.testing.assert_allclose(vias, np.array(rec["vias"]), rtol=1e-9, atol=1e-10)
+    else:   # CEM (ranking of a seeded population) and Nelder-Mead (simplex comparisons): the same candidates, bitwise
+        np.testing.assert_array_equal(vias, np.array(rec["vias"]))
     for k, v in ref.items():
         if isinstance(v, float) and k not in ("fun",):
-            assert info[k] == pytest.approx(v, rel=2e-5, abs=1e-7), k
+            assert info[k] == pytest.approx(v, rel=1e-9, abs=1e-10), k
         elif isinstance(v, list) and v and isinstance(v[0], float):
-            np.testing.assert_allclose(np.asarray(info[k], dtype=float), np.asarray(v), rtol=1e-5, atol=1e-5)
-    np.testing.assert_allclose(res[0](np.linspace(0.0, 1.0, 7)), np.array(rec["curve_at_u"]), rtol=1e-5, atol=1e-6)
+            np.testing.assert_allclose(np.asarray(info[k], dtype=float), np.asarray(v), rtol=1e-9, atol=1e-9)
+    np.testing.assert_allclose(res[0](np.linspace(0.0, 1.0, 7)), np.array(rec["curve_at_u"]), rtol=1e-9, atol=1e-10)
     if "yaw_fn" in info:
         assert np.asarray(info["yaw_fn"](0.5)).shape == (1,) and res[0](0.5).shape == (1, 3)
 

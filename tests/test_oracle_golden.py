@@ -76,6 +76,13 @@ def test_host_helpers_match_reference():
         P, ref = g2[f"P_{S}"], g2[f"out_{S}"]
         assert so.path_length(P) == pytest.approx(ref[0], rel=1e-14)
         assert so.mean_turn_angle_deg(P) == pytest.approx(ref[3], rel=1e-12, abs=1e-12)
+        # the other public helpers of the reference module (ref :63-79, :100-106, :117-145), same goldens
+        assert so.curvature_cost(P) == pytest.approx(ref[1], rel=1e-12, abs=1e-300)
+        assert so.yaw_smoothness_cost(g2[f"yaw_{S}"]) == pytest.approx(ref[2], rel=1e-13, abs=1e-300)
+        assert so._goal_approach_alignment_cost(P, g2[f"normals_{S}"], 0.12) == pytest.approx(ref[4], rel=1e-12, abs=1e-15)
+        assert so._goal_approach_alignment_cost(P, np.zeros((1, 3)), 0.12) == ref[5] == 0.0
+    np.testing.assert_array_equal(so._normalize([3.0, 0.0, 4.0]), [0.6, 0.0, 0.8])
+    np.testing.assert_array_equal(so._normalize(np.zeros(3)), np.zeros(3))
     for y, q in zip(g2["quat_yaw"], g2["quat"]):
         assert so.yaw_deg_to_quat(y) == tuple(q)
 
@@ -111,3 +118,25 @@ def test_reference_shaped_numpy_path_matches_the_reference_goldens(oracle_lib):
             assert cost == pytest.approx(gold[i, 0], rel=1e-10, abs=1e-12), (name, i)
             np.testing.assert_allclose(terms, gold[i, 1:], rtol=1e-9, atol=1e-12, err_msg=f"{name}[{i}]")
             np.testing.assert_allclose(d, ref["dist"][i], rtol=1e-12, atol=1e-13, err_msg=f"{name}[{i}] clearance")
+
+
+def test_path_distance_helpers_with_a_duck_typed_scene(oracle_lib):
+    """_path_distances / safety_cost (ref :148-211) against any scene object with the reference's two methods: the three
+    modes, the shape check of the per-sample quaternions and the squared-deficit sum."""
+    from motion_planning_amd import spline_opt as so
+
+    sc = H.load_scenarios()["front"]
+    scene = oracle_lib.OracleScene(H.blocks_from(sc["blocks"]))
+    P = np.linspace([-0.4, -0.2, 1.5], [0.0, 0.25, 0.45], 9)
+    d_pt = so._path_distances(scene, P)
+    np.testing.assert_array_equal(d_pt, [scene.signed_distance(p) for p in P])
+    yaw = np.linspace(0.0, 90.0, 9)
+    quats = np.array([so.yaw_deg_to_quat(y) for y in yaw])
+    d_box = so._path_distances(scene, P, moving_block_size=(0.6, 0.9, 0.6), moving_block_quats=quats, ignore_ids=["table"])
+    np.testing.assert_array_equal(d_box, [scene.signed_distance_block((0.6, 0.9, 0.6), p, tuple(q), ["table"]) for p, q in zip(P, quats)])
+    d_fix = so._path_distances(scene, P, moving_block_size=(0.6, 0.9, 0.6))
+    np.testing.assert_array_equal(d_fix, [scene.signed_distance_block((0.6, 0.9, 0.6), p) for p in P])
+    with pytest.raises(ValueError, match=r"moving_block_quats must have shape \(len\(P\), 4\)"):
+        so._path_distances(scene, P, moving_block_size=(0.6, 0.9, 0.6), moving_block_quats=quats[:-1])
+    want = float(np.sum(np.maximum(0.0, 0.3 - d_box) ** 2))
+    assert so.safety_cost(scene, P, 0.3, moving_block_size=(0.6, 0.9, 0.6), moving_block_quats=quats, ignore_ids=["table"]) == pytest.approx(want, rel=1e-15)

@@ -1,9 +1,18 @@
 #!/usr/bin/env python3
-"""BASELINE config 4: cluttered synthetic scene — 2,000 boxes, 256 samples/trajectory, 1,048,576 candidates
-sharded by index over the GPUs of the job (131,072 per GPU on 8 GPUs), fp64 cost + gradient.
+"""BASELINE config 4 as ONE job: cluttered synthetic scene — 2,000 boxes, 256 samples per trajectory, 1,048,576
+candidates sharded by index over the ranks of the job (131,072 per GPU on 8 GPUs), fp64 cost + gradient, ONE all-gather
+of the per-candidate (cost, min clearance, flags).
 
-  python tools/run_config4.py                     # one GPU's shard of the 8-GPU job
-  python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 tools/run_config4.py --total 1048576
+  python tools/run_config4.py                                   # one GPU's shard (rank 3 of 8) of the 8-GPU job
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 tools/run_config4.py
+
+Candidates are a function of their GLOBAL index (every rank draws the same stream and keeps rows [lo, hi) of it), so the
+gathered result can be checked row by row whatever the number of ranks: rank 0 re-evaluates a strided sample of ALL
+indices on its own GPU and compares the bytes with what the other ranks' GPUs sent (`cross_rank_mismatches` must be 0);
+`--dump` writes the gathered rows + inputs for an external checker (tests/test_gpu_evidence.py compares them with the
+brute-force oracle).  Rehearsal knobs for a one-GPU box: `--backend gloo --one-device` (every rank on cuda:0,
+collective staged through the host), `--force-dist` (communicator + collective with a single rank), and
+`--total/--boxes/--samples` for a reduced size.
 """
 import argparse
 import json
@@ -18,56 +27,97 @@ ROOT = Path(__file__).resolve().parents[1]
 sys.path.insert(0, str(ROOT))
 
 
+def global_candidates(problem, total, seed, dtype):
+    """Row i is candidate i of the job, identical on every rank (x0 + sigma0 * eps, one stream for the whole job)."""
+    rng = np.random.default_rng(seed)
+    eps = rng.normal(size=(total, problem.dim))
+    return np.ascontiguousarray(problem.x0[None, :] + eps * problem.sigma0[None, :], dtype=dtype)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--total", type=int, default=1_048_576)
-    ap.add_argument("--shards", type=int, default=8, help="shard count the total is divided by when run on fewer GPUs")
+    ap.add_argument("--boxes", type=int, default=2000)
+    ap.add_argument("--samples", type=int, default=256)
+    ap.add_argument("--shards", type=int, default=8, help="without torchrun: evaluate shard --shard-index of this many")
+    ap.add_argument("--shard-index", type=int, default=3)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--dtype", default="f64", choices=["f64", "f32"])
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"])
+    ap.add_argument("--one-device", action="store_true", help="every rank uses cuda:0 (rehearsal on a one-GPU box)")
+    ap.add_argument("--force-dist", action="store_true", help="run the collective path even with one rank")
+    ap.add_argument("--check-stride", type=int, default=4099)
+    ap.add_argument("--dump", default=None, help="rank 0 writes the gathered rows and the inputs to this .npz")
     args = ap.parse_args()
     import torch
     import torch.distributed as dist
 
     from motion_planning_amd import _native
     from motion_planning_amd.batch import DeviceBatch, allgather_results, pack_results, shard_bounds
-    from motion_planning_amd.synthetic import synthetic_candidates, synthetic_problem
+    from motion_planning_amd.synthetic import synthetic_problem
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    local = 0 if args.one_device else int(os.environ.get("LOCAL_RANK", "0"))
+    distributed = world > 1 or args.force_dist
+    if distributed:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
-    shards = world if world > 1 else args.shards
-    lo, hi = shard_bounds(args.total, rank if world > 1 else 0, shards)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group("gloo")
+    shards = world if distributed else args.shards
+    me = rank if distributed else args.shard_index
+    lo, hi = shard_bounds(args.total, me, shards)
     n = hi - lo
     dt = np.float64 if args.dtype == "f64" else np.float32
-    prob = synthetic_problem(_native.build_basis, 2000, 256, seed=1, size_range=(0.05, 0.3))
-    X = torch.from_numpy(synthetic_candidates(prob, n, seed=1000 + rank, dtype=dt)).cuda()
-    db = DeviceBatch(prob, n, device=local if world > 1 else 0, dtype=dt, want_grad=True)
+    prob = synthetic_problem(_native.build_basis, args.boxes, args.samples, seed=1, size_range=(0.05, 0.3))
+    Xall = global_candidates(prob, args.total, seed=4, dtype=dt)
+    X = torch.from_numpy(Xall[lo:hi]).cuda(local)
+    db = DeviceBatch(prob, max(n, 1), device=local, dtype=dt, want_grad=True)
     db.evaluate(X)
     torch.cuda.synchronize()
-    if world > 1:
+    if distributed:
         dist.barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         out = db.evaluate(X)
-    if world > 1:
-        full = allgather_results(pack_results(out["cost"], out["min_clear"], out["flags"]), args.total, rank, world)
+    full = None
+    if distributed:
+        packed = pack_results(out["cost"], out["min_clear"], out["flags"])
+        if args.backend == "gloo":
+            packed = packed.cpu()     # gloo moves host memory: a collective on device tensors hangs (round-1 rehearsal)
+        full = allgather_results(packed, args.total, rank, world)
     torch.cuda.synchronize()
-    if world > 1:
+    if distributed:
         dist.barrier()
     el = (time.perf_counter() - t0) / args.steps
     if rank == 0:
         fl = out["flags"].cpu().numpy()
-        flops = (256 * 2000 * 200 + 256 * 160 + 16 * 256 * prob.n_ctrl) * n * shards if world == 1 else None
-        print(json.dumps({"metric": "spline cost+grad evals/sec", "value": n * (world if world > 1 else 1) / el, "unit": "evals/s",
-                          "n_gpus": world, "candidates_this_gpu": n, "total_candidates": args.total, "s_per_pass": el,
-                          "dtype": args.dtype, "colliding_fraction": float((fl & 1).mean()),
-                          "config": {"workload": "BASELINE config 4: 2,000 boxes, 256 samples, 1M candidates sharded by index",
-                                     "algorithmic_flops_per_eval": 256 * 2000 * 200 + 256 * 160 + 16 * 256 * prob.n_ctrl}}))
+        line = {"metric": "spline cost+grad evals/sec", "value": n * (world if distributed else 1) / el, "unit": "evals/s",
+                "n_gpus": world, "candidates_this_rank": n, "total_candidates": args.total, "s_per_pass": el,
+                "dtype": args.dtype, "backend": args.backend if distributed else None,
+                "colliding_fraction": float((fl & 1).mean()),
+                "config": {"workload": f"BASELINE config 4: {args.boxes} boxes, {args.samples} samples, {args.total} candidates "
+                                       f"sharded by index over {shards} ranks"}}
+        if full is not None:
+            # cross-rank check: a strided sample of ALL global indices evaluated again on THIS rank's GPU must equal,
+            # byte for byte, the rows the owning ranks sent through the collective
+            idx = np.arange(0, args.total, max(1, args.check_stride))
+            chk = DeviceBatch(prob, len(idx), device=local, dtype=dt, want_grad=True)   # the same kernel variant as the job
+            o = chk.evaluate(torch.from_numpy(Xall[idx]).cuda(local))
+            mine = pack_results(o["cost"], o["min_clear"], o["flags"]).cpu().numpy()
+            got = full.cpu().numpy()[idx]
+            line["cross_rank_checked"] = int(len(idx))
+            line["cross_rank_mismatches"] = int((mine.view(np.uint8) != got.view(np.uint8)).any(axis=1).sum())
+            chk.close()
+            if args.dump:
+                np.savez(args.dump, rows=full.cpu().numpy(), X=Xall, boxes=prob.boxes, lo=lo, hi=hi)
+        print(json.dumps(line))
     db.close()
-    if world > 1:
+    if distributed:
+        dist.barrier()
         dist.destroy_process_group()
 
 
