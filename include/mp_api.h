@@ -221,6 +221,31 @@ int mp_eval(mp_ctx *ctx, int64_t n, const void *X, const int32_t *task_of, void 
             void *terms, void *grad, void *min_clear, uint8_t *flags, void *dist, int mem);
 int mp_set_cands_per_task(mp_ctx *ctx, int64_t cands_per_task);
 
+/* ---- mp_eval for callers that cannot allocate ------------------------------------
+ * No counterpart in the reference.  For callers that must not reach hipMalloc / hipFree:
+ * code under HIP graph capture, tight serving loops, harnesses that forbid allocation.
+ *
+ * Same computation as mp_eval(..., MP_MEM_DEVICE) for the box model, always through the
+ * split kernels (clearance_kernel writes the [n x S'] clearance / deciding-box tables,
+ * eval_kernel reads them): the tables live in a file-scope __device__ array of
+ * MP_NOALLOC_SCRATCH_BYTES that every GPU the library runs on holds until the process
+ * ends (its address is resolved once per device in mp_create).  The call allocates
+ * nothing and frees nothing; results are bit-identical to mp_eval's.
+ *
+ *   X, task_of, cost, grad, min_clear, flags: DEVICE pointers, as in mp_eval (grad,
+ *   min_clear, flags, task_of may be NULL); asynchronous on the context's stream.
+ *   Limit: n * S' * (sizeof(T) + 4) (+ 255 bytes of alignment) <= MP_NOALLOC_SCRATCH_BYTES,
+ *   i.e. fp64: 43,690 candidates at S' = 64, 10,922 at S' = 256; larger batches return
+ *   MP_E_ARG with the sizes in mp_last_error.  Point model: MP_E_UNSUPPORTED (its
+ *   kernels have no scratch; mp_eval never allocates for it).
+ *   All calls on one GPU share that GPU's array, which keeps the last call's contents
+ *   (nothing in it needs clearing: every entry a call reads it has written before):
+ *   calls that overlap on one GPU — two contexts, two streams — race on it; serialise
+ *   them, or use mp_eval for all but one. */
+#define MP_NOALLOC_SCRATCH_BYTES (32u << 20)
+int mp_eval_noalloc(mp_ctx *ctx, int64_t n, const void *X, const int32_t *task_of, void *cost,
+                    void *grad, void *min_clear, uint8_t *flags);
+
 /* ---- batched distance queries --------------------------------------------------
  * mp_point_sdf: Scene.signed_distance (geom/scene.py:50-68) for n points [n x 3].
  * mp_box_sdf:   Scene.signed_distance_block (geom/scene.py:70-122) for n poses of a

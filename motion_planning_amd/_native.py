@@ -63,12 +63,13 @@ def load():
     lib.mp_get_basis.argtypes = [vp, vp, vp]
     lib.mp_set_cands_per_task.argtypes = [vp, i64]
     lib.mp_eval.argtypes = [vp, i64, vp, vp, vp, vp, vp, vp, vp, vp, C.c_int]
+    lib.mp_eval_noalloc.argtypes = [vp, i64, vp, vp, vp, vp, vp, vp]
     lib.mp_point_sdf.argtypes = [vp, i64, vp, C.c_double, i32, i32, vp, C.c_int]
     lib.mp_box_sdf.argtypes = [vp, i64, vp, vp, vp, i32, i32, vp, C.c_int]
     lib.mp_cem_solve.argtypes = [vp, i64, vp, vp, vp, C.POINTER(abi.MpCemOptions), vp, vp, vp, vp, vp, vp, C.c_int]
     for name in ("mp_create", "mp_destroy", "mp_set_stream", "mp_use_own_stream", "mp_synchronize", "mp_timer_start", "mp_timer_stop",
                  "mp_set_scene", "mp_set_problem", "mp_build_basis", "mp_get_basis", "mp_set_cands_per_task",
-                 "mp_eval", "mp_point_sdf", "mp_box_sdf", "mp_cem_solve"):
+                 "mp_eval", "mp_eval_noalloc", "mp_point_sdf", "mp_box_sdf", "mp_cem_solve"):
         getattr(lib, name).restype = C.c_int
     if lib.mp_api_version() != abi.MP_API_VERSION:
         raise ImportError("libmp_hip.so was built from a different mp_api.h version")
@@ -213,6 +214,14 @@ class Context:
         self._check(self.lib.mp_eval(self._h, int(n), vp(X_ptr), vp(task_of_ptr or 0), vp(cost_ptr), vp(terms_ptr or 0),
                                      vp(grad_ptr or 0), vp(minc_ptr or 0), vp(flags_ptr or 0), vp(dist_ptr or 0),
                                      abi.MP_MEM_DEVICE))
+
+    def eval_device_noalloc(self, n: int, X_ptr: int, cost_ptr: int, grad_ptr: int = 0, minc_ptr: int = 0, flags_ptr: int = 0,
+                            task_of_ptr: int = 0) -> None:
+        """mp_eval_noalloc: the device-pointer call whose split-mode tables live in the library's static device array
+        (no hipMalloc / hipFree on the way; box model; at most MP_NOALLOC_SCRATCH_BYTES of tables)."""
+        vp = C.c_void_p
+        self._check(self.lib.mp_eval_noalloc(self._h, int(n), vp(X_ptr), vp(task_of_ptr or 0), vp(cost_ptr), vp(grad_ptr or 0),
+                                             vp(minc_ptr or 0), vp(flags_ptr or 0)))
 
     # -- distance queries --
     def point_sdf(self, pts: np.ndarray, radius: float = 1e-6, box_begin: int = 0, box_count: Optional[int] = None):

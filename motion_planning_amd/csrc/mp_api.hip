@@ -17,7 +17,14 @@
 #include "../../include/mp_api.h"
 #include "mp_kernels.hpp"
 
+// ---- mp_eval_noalloc: the split-mode tables in a file-scope device array ------------------------------------------
+// `scratch` is a host-side stand-in for the symbol, NOT a device address: host code only ever uses the per-device
+// address that hipGetSymbolAddress returned in mp_create (g_scratch_ptr); kernels get that pointer as an argument.
+static __device__ __align__(256) unsigned char scratch[MP_NOALLOC_SCRATCH_BYTES];
+
 namespace {
+
+void *g_scratch_ptr[64] = {nullptr};   // [device] address of that GPU's copy of `scratch` (each GPU has its own)
 
 thread_local char g_create_err[512] = "";
 
@@ -116,6 +123,9 @@ int upload(mp_ctx *ctx, DevBuf &b, const void *src, size_t bytes)
 }
 
 size_t esize(const mp_ctx *ctx) { return ctx->dtype == MP_F64 ? 8 : 4; }
+
+// layout of the static scratch array: [n x S'] clearances, then (256-byte aligned) [n x S'] deciding boxes
+size_t noalloc_arg_offset(size_t d_bytes) { return (d_bytes + 255) & ~(size_t)255; }
 
 constexpr size_t kPinnedCallBytes = (size_t)256 << 10;  // host-buffer calls up to this size go through pinned memory
 
@@ -492,7 +502,7 @@ int launch_eval_k(mp_ctx *ctx, const mp::EvalArgs<T> &args, int wpb, int blocks,
 template <typename T>
 int launch_eval(mp_ctx *ctx, long long n, const void *X, const int32_t *task_of, void *cost, void *terms, void *grad,
                 void *minc, uint8_t *flags, void *dist, int group_size = 0, const int *group_task = nullptr,
-                const uint8_t *group_done = nullptr)
+                const uint8_t *group_done = nullptr, void *ext_scratch = nullptr)
 {
     const mp_config &c = ctx->cfg;
     mp::EvalArgs<T> a{};
@@ -547,12 +557,18 @@ int launch_eval(mp_ctx *ctx, long long n, const void *X, const int32_t *task_of,
     if (c.model == MP_MODEL_BOX) {
         const size_t pre_bytes = (size_t)n * (size_t)c.n_safe * (sizeof(T) + sizeof(int));
         bool split = ctx->split_mode == 1 || (ctx->split_mode < 0 && (ctx->max_task_boxes >= 128 || (c.n_safe > 64 && ctx->max_task_boxes >= 32)));
+        if (ext_scratch) split = true;   // mp_eval_noalloc: always the split kernels, tables in the caller-independent static array
         if (split && pre_bytes <= ((size_t)16 << 30)) {
-            int rc = reserve(ctx, ctx->s_pre_d, (size_t)n * c.n_safe * sizeof(T));
-            if (rc) return rc;
-            if ((rc = reserve(ctx, ctx->s_pre_arg, (size_t)n * c.n_safe * sizeof(int)))) return rc;
-            a.pre_d = (T *)ctx->s_pre_d.p;
-            a.pre_arg = (int *)ctx->s_pre_arg.p;
+            if (ext_scratch) {
+                a.pre_d = (T *)ext_scratch;
+                a.pre_arg = (int *)((unsigned char *)ext_scratch + noalloc_arg_offset((size_t)n * c.n_safe * sizeof(T)));
+            } else {
+                int rc = reserve(ctx, ctx->s_pre_d, (size_t)n * c.n_safe * sizeof(T));
+                if (rc) return rc;
+                if ((rc = reserve(ctx, ctx->s_pre_arg, (size_t)n * c.n_safe * sizeof(int)))) return rc;
+                a.pre_d = (T *)ctx->s_pre_d.p;
+                a.pre_arg = (int *)ctx->s_pre_arg.p;
+            }
             const long long units = n * ((c.n_safe + 63) / 64);
             const int cblocks = (int)std::min<long long>((units + 3) / 4, (long long)ctx->num_cu * 32);
             const size_t clds = (size_t)4 * mp::clearance_lds_bytes_per_wave((int)sizeof(T));
@@ -746,6 +762,12 @@ int mp_create(int device_id, int dtype, mp_ctx **out)
     ctx->stream = ctx->own_stream;
     if ((e = hipEventCreate(&ctx->ev0)) != hipSuccess) return bail("hipEventCreate", e);
     if ((e = hipEventCreate(&ctx->ev1)) != hipSuccess) return bail("hipEventCreate", e);
+    if (device_id < 64 && !g_scratch_ptr[device_id]) {
+        // this GPU's copy of the static scratch array of mp_eval_noalloc (device_id is current here)
+        void *ptr = nullptr;
+        if ((e = hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch))) != hipSuccess) return bail("hipGetSymbolAddress(scratch)", e);
+        g_scratch_ptr[device_id] = ptr;
+    }
     *out = ctx;
     return MP_OK;
 }
@@ -1051,6 +1073,41 @@ int mp_eval(mp_ctx *ctx, int64_t n, const void *X, const int32_t *task_of, void 
     if (dist) HIP_TRY(ctx, hipMemcpyAsync(dist, d_dist, (size_t)n * c.n_safe * es, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return MP_OK;
+}
+
+int mp_eval_noalloc(mp_ctx *ctx, int64_t n, const void *X, const int32_t *task_of, void *cost, void *grad, void *min_clear,
+                    uint8_t *flags)
+{
+    DeviceGuard guard_;
+    int rc = guard_.enter(ctx);
+    if (rc) return rc;
+    if (!ctx->have_problem) return fail(ctx, MP_E_STATE, "mp_eval_noalloc: call mp_set_scene and mp_set_problem first");
+    if (n < 0 || (n > 0 && (!X || !cost))) return fail(ctx, MP_E_ARG, "mp_eval_noalloc: X and cost are required");
+    if (n == 0) return MP_OK;
+    const mp_config &c = ctx->cfg;
+    if (c.model != MP_MODEL_BOX)
+        return fail(ctx, MP_E_UNSUPPORTED, "mp_eval_noalloc: only the box model has kernels with a scratch table; for the point "
+                    "model mp_eval(MP_MEM_DEVICE) never allocates");
+    if (!task_of && ctx->n_tasks > 1) {
+        if (ctx->cands_per_task <= 0) return fail(ctx, MP_E_ARG, "mp_eval_noalloc: several tasks need task_of or mp_set_cands_per_task");
+        if ((n + ctx->cands_per_task - 1) / ctx->cands_per_task > ctx->n_tasks)
+            return fail(ctx, MP_E_ARG, "mp_eval_noalloc: n exceeds n_tasks * cands_per_task");
+    }
+    if (!task_of && ctx->n_tasks == 1 && ctx->cands_per_task > 0 && n > ctx->cands_per_task)
+        return fail(ctx, MP_E_ARG, "mp_eval_noalloc: n exceeds n_tasks * cands_per_task");
+    void *ptr = ctx->device < 64 ? g_scratch_ptr[ctx->device] : nullptr;
+    if (!ptr) return fail(ctx, MP_E_STATE, "mp_eval_noalloc: no scratch address for device %d", ctx->device);
+    const size_t es = esize(ctx), samples = (size_t)n * (size_t)c.n_safe;
+    const size_t need = noalloc_arg_offset(samples * es) + samples * sizeof(int);
+    if (need > (size_t)MP_NOALLOC_SCRATCH_BYTES)
+        return fail(ctx, MP_E_ARG, "mp_eval_noalloc: %lld candidates x %d collision samples need %zu bytes of scratch, the static "
+                    "array holds %zu (MP_NOALLOC_SCRATCH_BYTES): split the batch or call mp_eval", (long long)n, c.n_safe, need,
+                    (size_t)MP_NOALLOC_SCRATCH_BYTES);
+    // Nothing in the tables has to start at zero: clearance_kernel writes every (candidate, sample) entry that
+    // eval_kernel reads afterwards on the same stream; entries of the previous call beyond n x S' are never read.
+    return ctx->dtype == MP_F64
+               ? launch_eval<double>(ctx, n, X, task_of, cost, nullptr, grad, min_clear, flags, nullptr, 0, nullptr, nullptr, ptr)
+               : launch_eval<float>(ctx, n, X, task_of, cost, nullptr, grad, min_clear, flags, nullptr, 0, nullptr, nullptr, ptr);
 }
 
 static int sdf_common(mp_ctx *ctx, int64_t n, int32_t box_begin, int32_t box_count, int mem, const char *who)
