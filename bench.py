@@ -40,7 +40,7 @@ def algorithmic_flops(S, Sp, B, C):
     return Sp * B * 200 + S * 160 + 16 * S * C
 
 
-def cpu_baseline(problem, X, budget_s=8.0):
+def cpu_baseline(problem, X, budget_s=4.0):
     """The C oracle ("port") on the box's host cores over a bounded sample of the same workload: first on ONE
     core (the reference itself is single-threaded Python), then on `cores` threads (ctypes releases the GIL, every
     call owns its workspace) — the second figure is the reported value, the honest best-CPU number."""
@@ -84,6 +84,70 @@ def cpu_baseline(problem, X, budget_s=8.0):
                       f"{m} candidates in 2 s on one core"}
 
 
+def _rate(db, X, steps):
+    db.evaluate(X)
+    db.ctx.timer_start()
+    for _ in range(steps):
+        db.evaluate(X)
+    return X.shape[0] / (db.ctx.timer_stop() / steps * 1e-3)
+
+
+def workload_sweep(_native, problem, Xh, np_dtype, steps):
+    """The headline shape (65,536 x 64 samples x 50 boxes, cost + gradient) over the workload distribution: other scene
+    seeds, tighter / wider candidate clouds, and a mostly collision-free batch (what a late CEM generation or a refined
+    population looks like: small positive clearances, more pairs survive the culling bound).  Exact pairs per candidate
+    come from tools/workload_stats.py (-DMP_STATS build) when its summary is committed under profiles/."""
+    import torch
+
+    from motion_planning_amd.batch import DeviceBatch, refine_gradient
+    from motion_planning_amd.synthetic import synthetic_candidates, synthetic_problem
+
+    stats = {}
+    sfile = ROOT / "profiles" / "r02_workload_stats.json"
+    if sfile.exists():
+        try:
+            stats = json.loads(sfile.read_text())
+        except Exception:
+            stats = {}
+    rows = []
+
+    def measure(name, prob, Xn):
+        Xd = torch.from_numpy(np.ascontiguousarray(Xn, dtype=np_dtype)).cuda()
+        db = DeviceBatch(prob, Xd.shape[0], dtype=np_dtype, want_grad=True)
+        rate = _rate(db, Xd, steps)
+        torch.cuda.synchronize()
+        fl = db.flags.cpu().numpy()
+        row = {"case": name, "evals_per_s": rate, "colliding_fraction": float((fl & 1).mean()),
+               "feasible_fraction": float(((fl & 2) != 0).mean())}
+        if name in stats:
+            row["exact_pairs_per_candidate"] = stats[name].get("exact_pairs_per_candidate")
+        rows.append(row)
+        return db
+
+    for seed in (1, 2, 3):
+        p = synthetic_problem(_native.build_basis, N_BOXES, N_SAMPLES, seed=seed)
+        measure(f"scene_seed_{seed}", p, synthetic_candidates(p, N_CAND, seed=200 + seed)).close()
+    rng = np.random.default_rng(300)
+    eps = rng.normal(size=(N_CAND, problem.dim))
+    for scale in (0.25, 1.0, 2.0):
+        measure(f"spread_{scale:g}_sigma", problem, problem.x0[None, :] + scale * eps * problem.sigma0[None, :]).close()
+    # a >= 90 % feasible batch: descend a small cloud with the analytic gradient, keep the feasible survivors, refill the
+    # batch with slightly jittered copies of them
+    db = DeviceBatch(problem, N_CAND, dtype=np_dtype, want_grad=True)
+    seedX = torch.from_numpy(np.ascontiguousarray(Xh[:8192], dtype=np_dtype)).cuda()
+    ref = refine_gradient(db, seedX, iters=40)
+    ok = (ref["flags"] & 2) != 0
+    db.close()
+    if int(ok.sum()) >= 64:
+        surv = ref["x"][ok].cpu().numpy().astype(np.float64)
+        pick = rng.integers(0, surv.shape[0], size=N_CAND)
+        Xf = surv[pick] + 0.01 * rng.normal(size=(N_CAND, problem.dim)) * problem.sigma0[None, :]
+        measure("refined_mostly_feasible", problem, Xf).close()
+    vals = sorted(r["evals_per_s"] for r in rows)
+    return {"cases": rows, "min_evals_per_s": vals[0], "median_evals_per_s": vals[len(vals) // 2], "max_evals_per_s": vals[-1],
+            "shape": "65,536 candidates x 64 samples x 50 boxes, fp64 cost + gradient, one MI355X"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -92,6 +156,10 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--profile-mode", action="store_true",
+                    help="only the W + K launches of the headline kernel (what tools/pmc_passes.sh and the rocprofv3 --stats run "
+                         "profile): no side metrics, no CPU baseline")
+    ap.add_argument("--sustained-s", type=float, default=1.0, help="length of the sustained leg after the headline (N = 1)")
     ap.add_argument("--dtype", default="f64", choices=["f64", "f32"])
     args = ap.parse_args()
 
@@ -185,34 +253,62 @@ def main():
         elapsed = float(t.item())
 
     # roofline of the dominant kernel: kern_ms = HIP-event time of the timed region / K (all K launches are on one stream,
-    # back to back; with N > 1 the gathers run on RCCL's stream beside them)
-    flops = algorithmic_flops(N_SAMPLES, N_SAMPLES, N_BOXES, problem.n_ctrl) * N_CAND
+    # back to back; with N > 1 the gathers run on RCCL's stream beside them).  `achieved` is EXECUTED FP64 work: the typed
+    # VALU instruction counters of gfx950 (SQ_INSTS_VALU_{ADD,MUL,FMA,TRANS}_F64, one count per wave instruction = 64
+    # lanes, an FMA = 2 flop) collected by rocprofv3 on this same command (`bench.py --profile-mode`, tools/pmc_passes.sh ->
+    # profiles/r02_pmc/summary.json; the counts per launch are a property of the kernel and the batch, not of the clock),
+    # divided by the launch duration measured live here.
+    bf_flops = algorithmic_flops(N_SAMPLES, N_SAMPLES, N_BOXES, problem.n_ctrl) * N_CAND
     peak = FP64_VALU_PEAK_TFLOPS if args.dtype == "f64" else FP32_VALU_PEAK_TFLOPS
-    achieved = flops / (kern_ms * 1e-3) / 1e12
     es = 8 if args.dtype == "f64" else 4
     alg_bytes = (es * problem.dim + es * (problem.dim + 2) + 1) * N_CAND
-    traffic = None
-    tfile = ROOT / "profiles" / "traffic.json"
-    if tfile.exists():
-        try:
-            traffic = json.loads(tfile.read_text()).get(f"eval_kernel_{args.dtype}_bytes_per_launch")
-        except Exception:
-            traffic = None
-
-    executed = None
-    pfile = ROOT / "profiles" / "r01_pmc" / "summary.json"
+    traffic, executed, achieved, frac = None, None, None, None
+    pfile = ROOT / "profiles" / "r02_pmc" / "summary.json"
     if pfile.exists() and args.dtype == "f64":
         try:
             g = json.loads(pfile.read_text())["grad"]
-            executed = {"valu_insts_per_eval": g["SQ_INSTS_VALU"] / N_CAND, "salu_insts_per_eval": g["SQ_INSTS_SALU"] / N_CAND,
-                        "lds_insts_per_eval": g["SQ_INSTS_LDS"] / N_CAND,
-                        "valu_busy_frac": g["SQ_ACTIVE_INST_VALU"] * 4 / (g["GRBM_GUI_ACTIVE"] / 8 * 1024),
-                        "source": "profiles/r01_pmc/summary.json (rocprofv3 --pmc passes of tools/prof_run.py, same kernel and batch)"}
+            f64_insts = g["SQ_INSTS_VALU_ADD_F64"] + g["SQ_INSTS_VALU_MUL_F64"] + g["SQ_INSTS_VALU_FMA_F64"] + g["SQ_INSTS_VALU_TRANS_F64"]
+            f64_flops = 64.0 * (f64_insts + g["SQ_INSTS_VALU_FMA_F64"])          # an FMA counts twice
+            f32_flops = 64.0 * g.get("SQ_INSTS_VALU_FLOPS_FP32", 0.0)
+            achieved = f64_flops / (kern_ms * 1e-3) / 1e12
+            frac = achieved / peak
+            # every wave64 VALU instruction occupies its SIMD's 16-lane ALU for 4 cycles: issue utilisation of the vector
+            # ALUs = instructions x 4 cycles / (SIMDs x cycles of the launch)
+            cycles = g["GRBM_GUI_ACTIVE"] / 8.0       # the counter sums the 8 XCDs
+            executed = {"fp64_flops_per_launch": f64_flops, "fp64_flops_per_eval": f64_flops / N_CAND,
+                        "fp32_flops_per_launch": f32_flops,
+                        "valu_insts_per_eval": g["SQ_INSTS_VALU"] / N_CAND, "fp64_insts_per_eval": f64_insts / N_CAND,
+                        "salu_insts_per_eval": g["SQ_INSTS_SALU"] / N_CAND, "lds_insts_per_eval": g["SQ_INSTS_LDS"] / N_CAND,
+                        "valu_issue_util": g["SQ_ACTIVE_INST_VALU"] * 4 / (cycles * 1024),
+                        "wave_wait_frac": g["SQ_WAIT_ANY"] / g["SQ_WAVE_CYCLES"],
+                        "launch": "eval_kernel<double, 1, true, 0, false>, 65,536 candidates (this command's batch)",
+                        "source": "profiles/r02_pmc/summary.json (rocprofv3 --pmc passes over `bench.py --profile-mode`)"}
+            # HBM bytes per launch: FETCH_SIZE (KiB, x2 on gfx950 per MI355X_MICROARCH.md) + WRITE_SIZE (KiB), separate passes
+            traffic = int((2.0 * g["FETCH_SIZE"] + g["WRITE_SIZE"]) * 1024)
         except Exception:
-            executed = None
+            traffic, executed, achieved, frac = None, None, None, None
 
     extras = {}
+    if args.profile_mode:
+        if rank == 0:
+            print(json.dumps({"profile_mode": True, "kernel_ms": kern_ms, "ms_per_step": elapsed / args.steps * 1e3, "steps": args.steps}))
+        for d in dbs:
+            d.close()
+        if distributed:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
     if rank == 0 and world == 1:
+        # sustained leg: >= 1 s of back-to-back launches of the same step (the headline's K steps are a few ms after an
+        # idle phase; this is the settled-clock figure and what a GPU-busy sampler can see)
+        n_sus = max(args.steps, int(args.sustained_s / max(kern_ms * 1e-3, 1e-6)))
+        db.ctx.timer_start()
+        for i in range(n_sus):
+            db.evaluate(X)
+        sus_ms = db.ctx.timer_stop() / n_sus
+        extras["sustained_ms_per_step"] = sus_ms
+        extras["sustained_steps"] = n_sus
+        extras["sustained_evals_per_s"] = N_CAND / (sus_ms * 1e-3)
         db_c = DeviceBatch(problem, N_CAND, dtype=np_dtype, want_grad=False)
         db_c.evaluate(X)
         db_c.ctx.set_stream(torch.cuda.current_stream().cuda_stream)
@@ -248,9 +344,13 @@ def main():
                 tp = time.perf_counter() - tp
             extras["two_streams_evals_per_s"] = 2 * args.steps * N_CAND / tp
             db2.close()
+        db.evaluate(X)
+        torch.cuda.synchronize()
         fl = db.flags.cpu().numpy()
         extras["colliding_fraction"] = float((fl & 1).mean())
         extras["feasible_fraction"] = float(((fl & 2) != 0).mean())
+        if not args.no_cpu_baseline:
+            extras["workload_sweep"] = workload_sweep(_native, problem, Xh, np_dtype, max(20, args.steps // 4))
 
     # second headline metric (BASELINE config 5, bounded): scenarios solved per second, every rank its own scenarios
     # x 32 restarts of device-resident CEM to the reference stopping rule; not part of `value`
@@ -299,15 +399,20 @@ def main():
                        "candidates_per_gpu": N_CAND, "n_samples": N_SAMPLES, "n_boxes": N_BOXES, "dim": problem.dim,
                        "parallelism": f"index-sharded x{world}, async all-gather of (cost,min_clear,flags)"},
             "roofline": {"bound": "fp64_valu" if args.dtype == "f64" else "fp32_valu", "achieved": achieved, "peak": peak,
-                         "unit": "TFLOP/s", "frac": achieved / peak, "traffic": traffic,
-                         "kernel_ms": kern_ms, "algorithmic_flops_per_eval": flops // N_CAND,
+                         "unit": "TFLOP/s", "frac": frac, "traffic": traffic,
+                         "kernel_ms": kern_ms, "executed": executed,
                          "algorithmic_bytes_per_eval": alg_bytes // N_CAND,
-                         "hbm_achieved_GBps": alg_bytes / (kern_ms * 1e-3) / 1e9, "hbm_peak_GBps": HBM_PEAK_GBPS,
-                         "executed": executed,
+                         "hbm_algorithmic_GBps": alg_bytes / (kern_ms * 1e-3) / 1e9, "hbm_peak_GBps": HBM_PEAK_GBPS,
+                         "bruteforce_flops_per_eval": bf_flops // N_CAND,
+                         "bruteforce_equiv_tflops": bf_flops / (kern_ms * 1e-3) / 1e12,
+                         "algorithmic_speedup_vs_bruteforce": bf_flops / (kern_ms * 1e-3) / 1e12 / peak,
                          "note": "bound = FP64 vector ALU (SURVEY 8d: no MFMA-shaped work, 145 B/eval of HBM traffic); peak = "
-                                 "datasheet FP64 vector rate; achieved counts the ALGORITHMIC (brute-force) flops per launch, the "
-                                 "kernel culls most pair evaluations with a conservative bound, so frac is useful throughput "
-                                 "against the brute-force roofline, not ALU utilisation (see executed / DESIGN.md 4)"},
+                                 "datasheet FP64 vector rate.  achieved / frac = EXECUTED FP64 flop/s from the typed VALU counters "
+                                 "(null when profiles/r02_pmc is absent or dtype is not f64); valu_issue_util = share of vector-ALU "
+                                 "issue cycles in use (all instruction types).  The kernel culls ~92 % of the (sample, box) pair "
+                                 "evaluations with a conservative bound, so SURVEY's brute-force flop count F is not executed: "
+                                 "bruteforce_equiv_tflops = F x evals / time and algorithmic_speedup_vs_bruteforce = that / peak "
+                                 "(> 1 means faster than an ideal brute-force kernel) are throughput figures, not utilisation"},
             "extras": extras,
         }
         if world == 1 and not args.no_cpu_baseline:

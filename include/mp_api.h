@@ -30,9 +30,9 @@ extern "C" {
 
 /* ---- limits ------------------------------------------------------------------ */
 #define MP_MAX_CTRL 16    /* waypoints per spline (start + vias + goal)            */
-#define MP_MAX_SAMPLES 1024 /* n_samples_curve (gradient launches: the per-wave LDS slice
-                               must fit 160 KB, i.e. <= ~860 fp64 / ~1024 fp32 samples;
-                               larger ones return MP_E_UNSUPPORTED)              */
+#define MP_MAX_SAMPLES 1024 /* n_samples_curve (the per-wave LDS slice of a gradient launch,
+                               17 values per sample, must fit the CU's 160 KB: 1024 fp64
+                               samples are 153 KB, one wave per CU)               */
 #define MP_NTERMS 15      /* cost terms, order of the weighted sum spline_opt.py:605-621 */
 
 /* ---- error codes ------------------------------------------------------------- */

@@ -60,7 +60,7 @@ struct mp_ctx {
     int n_tasks = 0;
     long long cands_per_task = 0;
     std::vector<double> basis, basis_yaw;
-    DevBuf d_idx, d_mask, d_M, d_My, d_tsched, d_tasks;
+    DevBuf d_idx, d_inv, d_mask, d_M, d_My, d_tsched, d_tasks;
 
     // staging for MP_MEM_HOST calls
     DevBuf s_X, s_taskof, s_cost, s_terms, s_grad, s_minc, s_flags, s_dist, s_aux0, s_aux1;
@@ -510,13 +510,15 @@ int launch_eval(mp_ctx *ctx, long long n, const void *X, const int32_t *task_of,
     a.nyf = c.n_yaw_free; a.Sp = c.n_safe; a.last_cond = c.last_if_not_close; a.keep_n = c.keep_n;
     a.use_pref = c.use_pref; a.tail_start = c.tail_start; a.use_goal_target = c.use_goal_target;
     a.goal_tail_n = c.goal_tail_n; a.mask = c.term_mask;
-    a.lds_per_wave = mp::lds_bytes_per_wave(c.n_samples, (int)sizeof(T), grad != nullptr);
+    a.w_elems = mp::w_elems_for(c.n_ctrl, c.n_yaw_ctrl);
+    a.lds_per_wave = mp::lds_bytes_per_wave(c.n_samples, (int)sizeof(T), grad != nullptr, a.w_elems);
     a.n_tasks = ctx->n_tasks;
     for (int i = 0; i < MP_NTERMS; ++i) a.w[i] = (T)c.weights[i];
     a.req = (T)c.required_clearance; a.pref = (T)c.preferred_clearance; a.appr_tgt = (T)c.approach_target;
     a.goal_tgt = (T)c.goal_clearance_target; a.radius = (T)c.point_radius;
     a.ax = (T)c.half_extents[0]; a.ay = (T)c.half_extents[1]; a.az = (T)c.half_extents[2];
-    a.idx_safe = (const int *)ctx->d_idx.p; a.idx_identity = ctx->idx_identity; a.amask = (const uint8_t *)ctx->d_mask.p;
+    a.du = T(1) / (T)(c.n_samples - 1); a.inv_du = T(1) / a.du; a.inv_h2 = T(1) / (T(2) * a.du);
+    a.idx_safe = (const int *)ctx->d_idx.p; a.inv_idx = (const int *)ctx->d_inv.p; a.idx_identity = ctx->idx_identity; a.amask = (const uint8_t *)ctx->d_mask.p;
     a.M = (const T *)ctx->d_M.p; a.My = (const T *)ctx->d_My.p; a.tsched = (const T *)ctx->d_tsched.p;
     a.tasks = (const mp::DevTask<T> *)ctx->d_tasks.p; a.boxes = (const mp::BoxRec<T> *)ctx->boxes.p;
     a.boxes32 = (const mp::BoxRec32 *)ctx->boxes32.p; a.pairs = (const mp::BoxPair32 *)ctx->pairs32.p; a.groups = (const mp::BoxRec32 *)ctx->groups.p;
@@ -778,7 +780,7 @@ int mp_destroy(mp_ctx *ctx)
     DeviceGuard guard_;
     (void)guard_.enter(ctx);
     hipStreamSynchronize(ctx->stream);
-    DevBuf *bufs[] = {&ctx->boxes, &ctx->boxes32, &ctx->pairs32, &ctx->groups, &ctx->d_idx, &ctx->d_mask, &ctx->d_M, &ctx->d_My, &ctx->d_tsched, &ctx->d_tasks,
+    DevBuf *bufs[] = {&ctx->boxes, &ctx->boxes32, &ctx->pairs32, &ctx->groups, &ctx->d_idx, &ctx->d_inv, &ctx->d_mask, &ctx->d_M, &ctx->d_My, &ctx->d_tsched, &ctx->d_tasks,
                       &ctx->s_X, &ctx->s_taskof, &ctx->s_cost, &ctx->s_terms, &ctx->s_grad, &ctx->s_minc,
                       &ctx->s_flags, &ctx->s_dist, &ctx->s_aux0, &ctx->s_aux1, &ctx->s_pre_d, &ctx->s_pre_arg, &ctx->tilt, &ctx->c_X, &ctx->c_vals, &ctx->c_minc,
                       &ctx->c_flags, &ctx->c_mu, &ctx->c_sigma, &ctx->c_bestx, &ctx->c_bestval, &ctx->c_prev, &ctx->c_bminc,
@@ -944,6 +946,9 @@ int mp_set_problem(mp_ctx *ctx, const mp_config *cfg, int32_t n_tasks, const mp_
     else if ((rc = build_basis(c.n_yaw_ctrl, std::min(3, c.n_yaw_ctrl - 1), c.n_samples, ctx->basis_yaw.data())))
         return fail(ctx, rc, "yaw basis construction failed");
     if ((rc = upload(ctx, ctx->d_idx, c.idx_safe, (size_t)c.n_safe * sizeof(int32_t)))) return rc;
+    std::vector<int32_t> inv((size_t)c.n_samples, -1);   // spline sample -> collision sample taken there
+    for (int k = 0; k < c.n_safe; ++k) inv[(size_t)c.idx_safe[k]] = k;
+    if ((rc = upload(ctx, ctx->d_inv, inv.data(), inv.size() * sizeof(int32_t)))) return rc;
     ctx->idx_identity = 1;
     for (int k = 0; k < c.n_safe; ++k)
         if (c.idx_safe[k] != k) { ctx->idx_identity = 0; break; }

@@ -13,6 +13,9 @@ namespace mp {
 #ifndef MP_MIN_WAVES
 #define MP_MIN_WAVES 3
 #endif
+#ifndef MP_GRAD64_WAVES
+#define MP_GRAD64_WAVES MP_MIN_WAVES   // waves per SIMD the fp64 gradient kernels are register-budgeted for
+#endif
 // Investigation builds only (tools/clearance_stats.py, tools/phase_clock.py build them into build_ab/):
 //   -DMP_STATS   work counters of the clearance phase (contended atomics: timings of such a build mean nothing)
 //   -DMP_PHASES  per-phase cycle clocks of eval_kernel, accumulated per wave and flushed once at kernel end
@@ -54,10 +57,13 @@ template <typename T> struct EvalArgs {
     int S, C, ff, nf, Cy, nyf, Sp, last_cond, keep_n, use_pref, tail_start, use_goal_target, goal_tail_n;
     unsigned mask;
     int lds_per_wave;  // bytes
+    int w_elems;       // elements of the waypoint table W in front of the records
     int n_tasks;
     T w[kNTerms];
     T req, pref, appr_tgt, goal_tgt, radius, ax, ay, az;
+    T du, inv_du, inv_h2;   // 1/(S-1), 1/du, 1/(2 du) in T arithmetic (host: the same correctly rounded divisions)
     const int *idx_safe;
+    const int *inv_idx;   // [S] collision sample of each spline sample, -1: none (read only when !idx_identity)
     int idx_identity;   // idx_safe[k] == k for every k (collision_check_subsample == 1): the table is not read
     const uint8_t *amask;
     const T *M;
@@ -88,7 +94,7 @@ template <typename T> struct EvalArgs {
 };
 
 // collision sample k -> spline sample (identity unless the path is subsampled for collision checks)
-template <typename T> __device__ __forceinline__ int sample_of(const EvalArgs<T> &a, int k)
+template <typename AT> __device__ __forceinline__ int sample_of(const AT &a, int k)
 {
     return a.idx_identity ? k : a.idx_safe[k];
 }
@@ -128,28 +134,39 @@ __device__ __forceinline__ void spline_sample(const T *__restrict__ m, const T *
 }
 
 // LDS slice of one wave (bytes).  Layout (S = samples, e = sizeof(T)):
-//   W[64] | P[3][S] YAW[S] | D[S] | CC[S] SS[S] | D1[3][S]                        (T; every launch: 10 arrays)
-//   | GP[3][S] GY[S] | GD[S] | A1[3][S] A2[3][S] | SEGW[S]                         (T; gradient launches: 12 more)
-//   | MINKEY[S] (u64) | ARG[S] (int) | QUEUE[128] (u32)
-// A cost-only launch (the CEM populations) needs less than half of a gradient launch's slice.
-__host__ __device__ inline int lds_arrays(bool grad) { return grad ? 22 : 10; }
-__host__ __device__ inline int lds_bytes_per_wave(int S, int e, bool grad)
+//   W[64] | REC[S][NREC]  | MINKEY[S] (u64) | ARG[S] (int) | QUEUE[128] (u32)
+// REC is an array of per-sample RECORDS (field f of sample s at REC[s * NREC + f]), not one array per quantity: a
+// lane addresses its sample once and reaches every field, and the fields of its neighbours s +- 1, through the
+// immediate offset of the ds instruction.  (One array per quantity needs one base address per array; with 22 of
+// them the scalar registers ran out and the compiler parked them in VGPR lanes, ~450 v_readlane per candidate.)
+// NREC is odd, so that the 64 lanes of a ds_read_b64 / ds_read_b32 of one field fall into distinct banks.
+//   fields of every launch:   P0 P1 P2 CC SS YW D D1x D1y D1z                       (10, NREC = 11)
+//   gradient launches add:    A1x A1y A1z A2x A2y A2z SEGW                          (17, NREC = 17)
+// d cost / d d_k of the gradient launches (GD) lives in the MINKEY array, which is dead once the clearances have been
+// read out of it; the clearance-chain gradient is formed inside the gather loop (no arrays of its own).
+// W holds 4 * max(C, Cy) elements, rounded up to 16 (EvalArgs::w_elems).
+// S = 64, fp64: 10.1 KB per wave with gradient (16 waves per CU fit the 160 KB), 6.7 KB without.
+enum RecField : int { kP0 = 0, kP1, kP2, kCC, kSS, kYW, kD, kD1x, kD1y, kD1z,
+                      kA1x, kA1y, kA1z, kA2x, kA2y, kA2z, kSEGW };
+__host__ __device__ constexpr int rec_fields(bool grad) { return grad ? 17 : 11; }
+__host__ __device__ inline int w_elems_for(int C, int Cy) { return ((4 * (C > Cy ? C : Cy)) + 15) & ~15; }
+__host__ __device__ inline int lds_bytes_per_wave(int S, int e, bool grad, int w_elems)
 {
-    int b = (64 + lds_arrays(grad) * S) * e;
+    int b = (w_elems + rec_fields(grad) * S) * e;
     b = (b + 7) & ~7;
     b += 8 * S + 4 * S + 4 * 128;
     return (b + 15) & ~15;
 }
+constexpr int kChunkRec = 7;   // record of clearance_kernel: P0 P1 P2 CC SS YW + 1 (odd)
 
 // ---- culled clearance of one chunk of <= 64 collision samples (one per lane) against a task's boxes ----
-// P0/P1/P2/YW are indexed by sample (LOCAL: by the lane's slot 0..63); CC/SS/MINKEY/ARG point at the chunk's
-// first slot.  SEED: start from an upper bound taken from one representative box per group (used by the split
+// REC: the per-sample records (fields kP0 kP1 kP2 kYW read at the sample, kCC kSS written at the collision
+// sample's own record; LOCAL: record = the lane's slot 0..63); MINKEY/ARG point at the chunk's first slot.  SEED: start from an upper bound taken from one representative box per group (used by the split
 // kernel, which serves every scene large enough to have groups).  On return MINKEY[slot] holds the ordered key of the scene value, ARG[slot] the deciding box
-// (-1: none) and CC/SS the (cos, sin) of the sample's yaw.
-template <typename T, int ROT, bool LOCAL, bool SEED>
-__device__ __forceinline__ void clearance_chunk(const EvalArgs<T> &a, const BoxRec<T> *boxes, const BoxRec32 *boxes32, const BoxPair32 *pairs,
-                                                const BoxRec32 *groups, int ngroups, int n_wide, int lane, int k0, int Sp, const T *P0,
-                                                const T *P1, const T *P2, const T *YW, T *CC, T *SS,
+// (-1: none) and the records' kCC/kSS the (cos, sin) of the sample's yaw.
+template <typename T, int ROT, bool LOCAL, bool SEED, int NREC, typename AT>
+__device__ __forceinline__ void clearance_chunk(const AT &a, const BoxRec<T> *boxes, const BoxRec32 *boxes32, const BoxPair32 *pairs,
+                                                const BoxRec32 *groups, int ngroups, int n_wide, int lane, int k0, int Sp, T *REC,
                                                 unsigned long long *MINKEY, int *ARG, unsigned int *QUEUE)
 {
     const float ax32 = (float)a.ax, ay32 = (float)a.ay, az32 = (float)a.az;
@@ -158,12 +175,14 @@ __device__ __forceinline__ void clearance_chunk(const EvalArgs<T> &a, const BoxR
     float px32 = 0.f, py32 = 0.f, pz32 = 0.f, exs = 0.f, eys = 0.f, ezs = 0.f, slack = 0.f;
     if (valid) {
         const int s = LOCAL ? lane : sample_of(a, k0 + lane);
+        const T *rs = REC + s * NREC;
+        T *rk = REC + (LOCAL ? lane : k0 + lane) * NREC;
         T c, sn;
-        yaw_rot(YW[s], c, sn);
-        CC[lane] = c; SS[lane] = sn;
+        yaw_rot(rs[kYW], c, sn);
+        rk[kCC] = c; rk[kSS] = sn;
         MINKEY[lane] = key_init<T>();
         ARG[lane] = -1;
-        px32 = (float)P0[s]; py32 = (float)P1[s]; pz32 = (float)P2[s];
+        px32 = (float)rs[kP0]; py32 = (float)rs[kP1]; pz32 = (float)rs[kP2];
         const float c32 = __builtin_fabsf((float)c), s32 = __builtin_fabsf((float)sn);
         slack = 2e-6f * (__builtin_fabsf(px32) + __builtin_fabsf(py32) + __builtin_fabsf(pz32) +
                          a.scene_radius + ax32 + ay32 + az32) + 1e-30f;
@@ -206,22 +225,24 @@ __device__ __forceinline__ void clearance_chunk(const EvalArgs<T> &a, const BoxR
             bb = (int)(e & 0xffffffu);
             const int ss = LOCAL ? kk : sample_of(a, k0 + kk);
             const BoxRec<T> bx = boxes[bb];
-            T qx = P0[ss], qy = P1[ss], qc = CC[kk], qs = SS[kk], bcx = bx.cx, bcy = bx.cy;
+            const T *rs = REC + ss * NREC, *rk = REC + (LOCAL ? kk : k0 + kk) * NREC;
+            const T qz = rs[kP2];
+            T qx = rs[kP0], qy = rs[kP1], qc = rk[kCC], qs = rk[kSS], bcx = bx.cx, bcy = bx.cy;
             if (ROT == 2 && box_is_tilted(bx)) {   // general rotation: the (large, rare) exact OBB routine
-                key = tilt_key(qx, qy, P2[ss], qc, qs, a.ax, a.ay, a.az, bx, a.tilt);
+                key = tilt_key(qx, qy, qz, qc, qs, a.ax, a.ay, a.az, bx, a.tilt);
             } else {
                 if (ROT) {   // evaluate the pair in the box's own frame
                     to_box_frame(bx, qx, qy, qc, qs);
                     bcx = T(0); bcy = T(0);
                 }
                 Pose<T> ps;
-                pose_setup(ps, qx, qy, P2[ss], qc, qs, a.ax, a.ay);
+                pose_setup(ps, qx, qy, qz, qc, qs, a.ax, a.ay);
                 key = pair_key(ps, a.ax, a.ay, a.az, bcx, bcy, bx.cz, bx.hx, bx.hy, bx.hz);
             }
 #ifdef MP_STATS
             if (ROT == 0) {   // how many evaluated pairs needed the rectangle distance (xy-separated), how many were overlaps
                 Pose<T> pst;
-                pose_setup(pst, qx, qy, P2[ss], qc, qs, a.ax, a.ay);
+                pose_setup(pst, qx, qy, qz, qc, qs, a.ax, a.ay);
                 PairOut<T> po;
                 pair_axes(pst, a.ax, a.ay, a.az, bcx, bcy, bx.cz, bx.hx, bx.hy, bx.hz, po);
                 if (po.gsat > T(0)) atomicAdd(&g_stats[5], 1ull);
@@ -257,8 +278,9 @@ __device__ __forceinline__ void clearance_chunk(const EvalArgs<T> &a, const BoxR
         bool need = aabb_lb2(mlox, mloy, mloz, mhix, mhiy, mhiz, bx) <= U32;
         if (need && a.ax > T(1e-3) && a.ay > T(1e-3)) {
             const int sw = LOCAL ? lane : sample_of(a, k0 + lane);
-            const T gz = mp_abs(P2[sw] - eb.cz) - (a.az + eb.hz);
-            if (mp_abs(P0[sw] - eb.cx) <= eb.hx && mp_abs(P1[sw] - eb.cy) <= eb.hy && gz > T(0)) {
+            const T *rw = REC + sw * NREC;
+            const T gz = mp_abs(rw[kP2] - eb.cz) - (a.az + eb.hz);
+            if (mp_abs(rw[kP0] - eb.cx) <= eb.hx && mp_abs(rw[kP1] - eb.cy) <= eb.hy && gz > T(0)) {
                 MINKEY[lane] = kSepBit | Key<T>::bits(mp_fma(gz, gz, T(0)));   // the slot is still at its initial value
                 ARG[lane] = bi;
                 U32 = __builtin_fminf(U32, (float)key_to_sep2<T>(MINKEY[lane]) * (1.0f + 4e-6f));
@@ -316,47 +338,68 @@ __device__ __forceinline__ void clearance_chunk(const EvalArgs<T> &a, const BoxR
 // ROT: 0 axis-aligned scene; 1 the scene holds yaw-rotated static boxes; 2 it also holds tilted ones (separate
 // instantiations keep the axis-aligned code as it was)
 // PRE: split mode, the clearance profile comes from clearance_kernel (box model only)
-// Waves per SIMD the register budget is sized for (measured, config 3): fp64 gradient kernels 3 (168 VGPRs; 2 and 4
-// are both ~20 % slower), fp64 cost-only kernels 4 (127 VGPRs; the CEM populations run on those), fp32 kernels 5
-// (<= 102 VGPRs: -6 % against 4).
+// Waves per SIMD the register budget is sized for (measured, config 3): fp64 gradient kernels 3 (<= 168 VGPRs), fp64
+// cost-only kernels 4 (127 VGPRs; the CEM populations run on those), fp32 kernels 5 (<= 96 VGPRs).  A 4-wave build of the
+// fp64 gradient kernel (128 VGPRs, ~90 B of scratch per lane; the S = 64 slice lets 16 waves share a CU) measured 10 %
+// faster at config 3 in round 2 but returned wrong gradients on the GPU (ROCm 7.2; the 3-wave build of the same source
+// passes every parity test), so it is not built: DESIGN.md 9.
 template <typename T, bool GRAD, int ROT = 0> constexpr int eval_min_waves()
 {
     return ROT == 2 ? 2   // the tilt routine is a real call: its registers count too
-                    : (sizeof(T) == 4 ? MP_MIN_WAVES + 2 : (GRAD ? MP_MIN_WAVES : MP_MIN_WAVES + 1));
+                    : (sizeof(T) == 4 ? MP_MIN_WAVES + 2 : (GRAD ? MP_GRAD64_WAVES : MP_MIN_WAVES + 1));
 }
 
 template <typename T, int MODEL, bool GRAD, int ROT, bool PRE>
-__global__ void __launch_bounds__(256, (eval_min_waves<T, GRAD, ROT>())) eval_kernel(const EvalArgs<T> a)
+__global__ void __launch_bounds__(256, (eval_min_waves<T, GRAD, ROT>())) eval_kernel(const EvalArgs<T> a_by_value)
 {
+    // The arguments are read through the kernel-argument segment pointer (the explicit arguments start at offset 0),
+    // re-derived behind an opaque barrier at the start of every phase of the candidate loop (MP_ARGS_REFRESH).  Read as
+    // plain by-value fields, all ~120 dwords of EvalArgs are loaded once and held in scalar registers across the whole
+    // loop; there are 102 of those, so the compiler parked the excess in VGPR lanes (v_writelane once, ~450
+    // v_readlane per candidate: one in seven vector instructions of the kernel).  A phase now holds only what it
+    // uses; the re-reads are scalar loads that hit the scalar cache.
+    typedef const EvalArgs<T> __attribute__((address_space(4))) KArgs;
+    KArgs *kargs = (KArgs *)__builtin_amdgcn_kernarg_segment_ptr();
+    (void)a_by_value;
+#define a (*kargs)
+#define MP_ARGS_REFRESH() asm volatile("" : "+s"(kargs))
+    // the scalar arguments a phase may use, read together at its start (one batch of scalar loads; what a phase does not
+    // use is dropped by the compiler); `t` = the candidate's task
+#define MP_LOCALS                                                                                                          \
+    const int S = a.S, C = a.C, Cy = a.Cy, nf = a.nf, ff = a.ff, nyf = a.nyf, D = 3 * nf + nyf;                            \
+    const unsigned mask = a.mask;                                                                                          \
+    const int keep_n = a.keep_n, use_pref = a.use_pref, tail_start = a.tail_start, use_goal_target = a.use_goal_target,    \
+              goal_tail_n = a.goal_tail_n, last_cond = a.last_cond;                                                        \
+    const T du = a.du, inv_du = a.inv_du, inv_h2 = a.inv_h2, req = a.req, pref = a.pref, appr_tgt = a.appr_tgt,            \
+            goal_tgt = a.goal_tgt;                                                                                         \
+    T w[kNTerms];                                                                                                          \
+    _Pragma("unroll") for (int wi_ = 0; wi_ < kNTerms; ++wi_) w[wi_] = a.w[wi_];                                           \
+    const T *M = a.M, *My = a.My, *tsched = a.tsched;                                                                      \
+    const uint8_t *amask = a.amask;                                                                                        \
+    const DevTask<T> &tk = a.tasks[t];                                                                                     \
+    const BoxRec<T> *boxes = a.boxes + __builtin_amdgcn_readfirstlane(tk.box_begin);                                       \
+    (void)S; (void)C; (void)Cy; (void)nf; (void)ff; (void)nyf; (void)D; (void)mask; (void)keep_n; (void)use_pref;          \
+    (void)tail_start; (void)use_goal_target; (void)goal_tail_n; (void)last_cond; (void)du; (void)inv_du; (void)inv_h2;     \
+    (void)req; (void)pref; (void)appr_tgt; (void)goal_tgt; (void)w; (void)M; (void)My; (void)tsched; (void)amask;          \
+    (void)tk; (void)boxes
     extern __shared__ __align__(16) unsigned char smem_raw[];
     const int lane = threadIdx.x & 63;
     const int wib = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int wpb = (int)(blockDim.x >> 6);
-    const int S = a.S, C = a.C, Cy = a.Cy, nf = a.nf, ff = a.ff, nyf = a.nyf;
-    const int D = 3 * nf + nyf;
+    const int S_layout = a.S;   // inside the candidate loop every argument is re-read per phase (MP_LOCALS)
     T *base = reinterpret_cast<T *>(smem_raw + (size_t)wib * a.lds_per_wave);
     T *W = base;
-    T *P0 = W + 64, *P1 = P0 + S, *P2 = P1 + S, *YW = P2 + S;
-    T *Dd = YW + S;
-    T *CC = Dd + S, *SS = CC + S;
-    T *D1x = SS + S, *D1y = D1x + S, *D1z = D1y + S;
-    // gradient launches only (the slice of a cost-only launch ends here)
-    T *G0 = D1z + S, *G1 = G0 + S, *G2 = G1 + S, *GY = G2 + S;
-    T *GD = GY + S;
-    T *A1x = GD + S, *A1y = A1x + S, *A1z = A1y + S;
-    T *A2x = A1z + S, *A2y = A2x + S, *A2z = A2y + S;
-    T *SEGW = A2z + S;
+    constexpr int NREC = rec_fields(GRAD);
+    T *REC = W + a.w_elems;
+#define RF(s_, f_) REC[(s_) * NREC + (f_)]
     unsigned long long *MINKEY = reinterpret_cast<unsigned long long *>(
-        smem_raw + (size_t)wib * a.lds_per_wave + (((64 + lds_arrays(GRAD) * S) * sizeof(T) + 7) & ~(size_t)7));
-    int *ARG = reinterpret_cast<int *>(MINKEY + S);
-    unsigned int *QUEUE = reinterpret_cast<unsigned int *>(ARG + S);
-    const unsigned mask = a.mask;
-    const T du = T(1) / (T)(S - 1);
-    // the stencils of np.gradient multiply by these instead of dividing by du / 2du (<= 1 ulp apart)
-    const T inv_du = T(1) / du, inv_h2 = T(1) / (T(2) * du);
-
+        smem_raw + (size_t)wib * a.lds_per_wave + (((a.w_elems + NREC * S_layout) * sizeof(T) + 7) & ~(size_t)7));
+    int *ARG = reinterpret_cast<int *>(MINKEY + S_layout);
+    unsigned int *QUEUE = reinterpret_cast<unsigned int *>(ARG + S_layout);
+    T *GDa = reinterpret_cast<T *>(MINKEY);   // d cost / d d_k, written after the clearances have left MINKEY
     MP_PHASE_DECL;
     for (long long cand = (long long)blockIdx.x * wpb + wib; cand < a.n; cand += (long long)gridDim.x * wpb) {
+        MP_ARGS_REFRESH();
         long long tl;
         if (a.group_size > 0) {
             const long long grp = cand / a.group_size;
@@ -375,18 +418,23 @@ __global__ void __launch_bounds__(256, (eval_min_waves<T, GRAD, ROT>())) eval_ke
                 if (a.flags) a.flags[cand] = 0;
             }
             if (a.terms && lane < kNTerms) a.terms[cand * kNTerms + lane] = nan;
+            const int D = 3 * a.nf + a.nyf;
             if (GRAD) for (int o = lane; o < D; o += 64) a.grad[cand * D + o] = nan;
             if (a.dist) for (int k = lane; k < a.Sp; k += 64) a.dist[cand * a.Sp + k] = nan;
             continue;
         }
         const int t = __builtin_amdgcn_readfirstlane((int)tl);
-        const DevTask<T> &tk = a.tasks[t];
-        const T *x = a.X + cand * D;
-        const int nb = __builtin_amdgcn_readfirstlane(tk.box_count);
-        const int box_begin = __builtin_amdgcn_readfirstlane(tk.box_begin);
-        const BoxRec<T> *boxes = a.boxes + box_begin;
+        // state that crosses the phases below
+        T t_len = T(0), t_ys = T(0), t_mono = T(0), t_sched = T(0), t_curv = T(0);
+        T t_safe = T(0), t_pref = T(0), t_reb = T(0), t_gc = T(0), t_gt = T(0), t_ac = T(0), t_acol = T(0);
+        T t_via = T(0), t_ydev = T(0), t_gn = T(0), gnx = T(0), gny = T(0), gnz = T(0);
+        T mc = Lim<T>::inf();
+        int Sp = 0, gn_first = 0;
 
         MP_PHASE_INIT;
+        {
+        MP_LOCALS;
+        const T *x = a.X + cand * D;
         // ---- waypoint table W[j][0..2] = position rows, W[j][3] = yaw controls ----
         {
             const int rows = C > Cy ? C : Cy;
@@ -406,53 +454,59 @@ __global__ void __launch_bounds__(256, (eval_min_waves<T, GRAD, ROT>())) eval_ke
         // ---- spline samples Q = M W (fixed fma chain over the waypoints) ----
         for (int s = lane; s < S; s += 64) {
             T px, py, pz, yw;
-            spline_sample(a.M + (size_t)s * C, a.My + (size_t)s * Cy, C, Cy, W, px, py, pz, yw);
-            P0[s] = px; P1[s] = py; P2[s] = pz; YW[s] = yw;
-            if (GRAD) { G0[s] = T(0); G1[s] = T(0); G2[s] = T(0); GY[s] = T(0); }
+            spline_sample(M + (size_t)s * C, My + (size_t)s * Cy, C, Cy, W, px, py, pz, yw);
+            RF(s, kP0) = px; RF(s, kP1) = py; RF(s, kP2) = pz; RF(s, kYW) = yw;
         }
         wave_lds_sync();
 
+        }
         MP_PHASE(0);  // waypoints + spline
+        MP_ARGS_REFRESH();
+        {
+        MP_LOCALS;
         // ---- per-sample geometric terms, pass 1 ----
-        T t_len = T(0), t_ys = T(0), t_mono = T(0), t_sched = T(0), t_curv = T(0);
         const T y0 = tk.yaw_ctrl[0], y1 = tk.yaw_ctrl[Cy - 1];
         for (int s = lane; s < S; s += 64) {
-            const T px = P0[s], py = P1[s], pz = P2[s], yw = YW[s];
+            const T px = RF(s, kP0), py = RF(s, kP1), pz = RF(s, kP2), yw = RF(s, kYW);
             if (s + 1 < S) {
-                T ex = P0[s + 1] - px, ey = P1[s + 1] - py, ez = P2[s + 1] - pz;
+                T ex = RF(s + 1, kP0) - px, ey = RF(s + 1, kP1) - py, ez = RF(s + 1, kP2) - pz;
                 T n, inv_n;
                 sqrt_rsqrt(ex * ex + ey * ey + ez * ez, n, inv_n);
                 t_len += n;
-                if (GRAD) SEGW[s] = n > T(0) ? a.w[0] * inv_n : T(0);  // w_len / |segment s|, reused by the reverse sweep
-                T dy = YW[s + 1] - yw;
+                if (GRAD) RF(s, kSEGW) = n > T(0) ? w[0] * inv_n : T(0);  // w_len / |segment s|, reused by the reverse sweep
+                T dy = RF(s + 1, kYW) - yw;
                 T e = npmax0(tk.yaw_inc ? -dy : dy);
                 t_mono += e * e;
             }
             if (s + 2 < S) {
-                T e = yw - T(2) * YW[s + 1] + YW[s + 2];
+                T e = yw - T(2) * RF(s + 1, kYW) + RF(s + 2, kYW);
                 t_ys += e * e;
             }
             {
-                T target = y0 + (y1 - y0) * a.tsched[s];
+                T target = y0 + (y1 - y0) * tsched[s];
                 T e = yw - target;
                 t_sched += e * e;
             }
             if (S >= 3) {  // np.gradient(P, du): one-sided at the ends, central inside
                 const int lo = s == 0 ? 0 : s - 1, hi = s == S - 1 ? s : s + 1;
                 const T sc = (s == 0 || s == S - 1) ? inv_du : inv_h2;
-                D1x[s] = (P0[hi] - P0[lo]) * sc; D1y[s] = (P1[hi] - P1[lo]) * sc; D1z[s] = (P2[hi] - P2[lo]) * sc;
+                RF(s, kD1x) = (RF(hi, kP0) - RF(lo, kP0)) * sc; RF(s, kD1y) = (RF(hi, kP1) - RF(lo, kP1)) * sc; RF(s, kD1z) = (RF(hi, kP2) - RF(lo, kP2)) * sc;
             }
         }
         wave_lds_sync();
+        }
         MP_PHASE(1);  // pass 1
+        MP_ARGS_REFRESH();
+        {
+        MP_LOCALS;
         // ---- curvature, pass 2 (second np.gradient) ----
         if ((mask & (1u << 1)) && S >= 3) {
             const T eps = T(1e-9);
             for (int s = lane; s < S; s += 64) {
-                const T v1x = D1x[s], v1y = D1y[s], v1z = D1z[s];
+                const T v1x = RF(s, kD1x), v1y = RF(s, kD1y), v1z = RF(s, kD1z);
                 const int lo = s == 0 ? 0 : s - 1, hi = s == S - 1 ? s : s + 1;
                 const T sc = (s == 0 || s == S - 1) ? inv_du : inv_h2;
-                const T v2x = (D1x[hi] - D1x[lo]) * sc, v2y = (D1y[hi] - D1y[lo]) * sc, v2z = (D1z[hi] - D1z[lo]) * sc;
+                const T v2x = (RF(hi, kD1x) - RF(lo, kD1x)) * sc, v2y = (RF(hi, kD1y) - RF(lo, kD1y)) * sc, v2z = (RF(hi, kD1z) - RF(lo, kD1z)) * sc;
                 T speed, inv_speed;
                 sqrt_rsqrt(v1x * v1x + v1y * v1y + v1z * v1z, speed, inv_speed);
                 T cx = v1y * v2z - v1z * v2y, cy = v1z * v2x - v1x * v2z, cz = v1x * v2y - v1y * v2x;
@@ -464,7 +518,7 @@ __global__ void __launch_bounds__(256, (eval_min_waves<T, GRAD, ROT>())) eval_ke
                 if (GRAD) {
                     // f = |c|^2 speed / sp^6 with c = d1 x d2; adjoints of d1 and d2
                     const T inv_sp6 = inv_sp3 * inv_sp3;
-                    const T k = a.w[1] * du;
+                    const T k = w[1] * du;
                     const T f2 = k * T(2) * speed * inv_sp6;
                     const T gcx = f2 * cx, gcy = f2 * cy, gcz = f2 * cz;
                     T gs = cn2 * inv_sp6;
@@ -475,32 +529,36 @@ __global__ void __launch_bounds__(256, (eval_min_waves<T, GRAD, ROT>())) eval_ke
                     } else if (speed > T(0)) {
                         q = k * gs * inv_speed;
                     }
-                    A1x[s] = v2y * gcz - v2z * gcy + q * v1x;
-                    A1y[s] = v2z * gcx - v2x * gcz + q * v1y;
-                    A1z[s] = v2x * gcy - v2y * gcx + q * v1z;
-                    A2x[s] = gcy * v1z - gcz * v1y; A2y[s] = gcz * v1x - gcx * v1z; A2z[s] = gcx * v1y - gcy * v1x;
+                    RF(s, kA1x) = v2y * gcz - v2z * gcy + q * v1x;
+                    RF(s, kA1y) = v2z * gcx - v2x * gcz + q * v1y;
+                    RF(s, kA1z) = v2x * gcy - v2y * gcx + q * v1z;
+                    RF(s, kA2x) = gcy * v1z - gcz * v1y; RF(s, kA2y) = gcz * v1x - gcx * v1z; RF(s, kA2z) = gcx * v1y - gcy * v1x;
                 }
             }
         } else if (GRAD) {
             for (int s = lane; s < S; s += 64) {
-                A1x[s] = T(0); A1y[s] = T(0); A1z[s] = T(0);
-                A2x[s] = T(0); A2y[s] = T(0); A2z[s] = T(0);
+                RF(s, kA1x) = T(0); RF(s, kA1y) = T(0); RF(s, kA1z) = T(0);
+                RF(s, kA2x) = T(0); RF(s, kA2y) = T(0); RF(s, kA2z) = T(0);
             }
         }
 
+        }
         MP_PHASE(2);  // curvature
+        MP_ARGS_REFRESH();
+        {
+        MP_LOCALS;
         // ---- clearance profile d_safe ----
-        int Sp = a.Sp;
+        Sp = a.Sp;
         if (MODEL == 1 && PRE) {
             // split mode: the clearance profile was computed by clearance_kernel (one wave per 64-sample chunk)
             for (int k = lane; k < Sp; k += 64) {
                 const T d = a.pre_d[cand * a.Sp + k];
-                Dd[k] = d;
+                RF(k, kD) = d;
                 ARG[k] = a.pre_arg[cand * a.Sp + k];
                 if (GRAD) {
                     T c, sn;
-                    yaw_rot(YW[sample_of(a, k)], c, sn);
-                    CC[k] = c; SS[k] = sn;
+                    yaw_rot(RF(sample_of(a, k), kYW), c, sn);
+                    RF(k, kCC) = c; RF(k, kSS) = sn;
                 }
                 if (a.dist) a.dist[cand * a.Sp + k] = d;
             }
@@ -510,12 +568,12 @@ __global__ void __launch_bounds__(256, (eval_min_waves<T, GRAD, ROT>())) eval_ke
             const int ngroups = __builtin_amdgcn_readfirstlane(tk.group_count);
             const int n_wide = __builtin_amdgcn_readfirstlane(tk.n_wide);
             for (int k0 = 0; k0 < Sp; k0 += 64) {
-                clearance_chunk<T, ROT, false, false>(a, boxes, boxes32, a.pairs + __builtin_amdgcn_readfirstlane(tk.spair_begin), groups, ngroups, n_wide, lane, k0, Sp, P0, P1, P2, YW, CC + k0, SS + k0,
-                                               MINKEY + k0, ARG + k0, QUEUE);
+                clearance_chunk<T, ROT, false, false, NREC>(a, boxes, boxes32, a.pairs + __builtin_amdgcn_readfirstlane(tk.spair_begin), groups,
+                                                            ngroups, n_wide, lane, k0, Sp, REC, MINKEY + k0, ARG + k0, QUEUE);
                 const int k = k0 + lane;
                 if (k < Sp) {
                     const T d = key_to_distance<T>(MINKEY[k]);
-                    Dd[k] = d;
+                    RF(k, kD) = d;
                     if (a.dist) a.dist[cand * a.Sp + k] = d;
                 }
             }
@@ -523,81 +581,86 @@ __global__ void __launch_bounds__(256, (eval_min_waves<T, GRAD, ROT>())) eval_ke
             for (int k = lane; k < Sp; k += 64) {
                 const int s = sample_of(a, k);
                 int arg = -1;
-                const T d = point_distance(P0[s], P1[s], P2[s], boxes, nb, a.radius, ROT != 0, ROT == 2 ? a.tilt : nullptr, arg);
-                Dd[k] = d;
+                const T d = point_distance(RF(s, kP0), RF(s, kP1), RF(s, kP2), boxes, __builtin_amdgcn_readfirstlane(tk.box_count), a.radius, ROT != 0, ROT == 2 ? a.tilt : nullptr, arg);
+                RF(k, kD) = d;
                 ARG[k] = arg;
                 if (a.dist) a.dist[cand * a.Sp + k] = d;
             }
         }
         wave_lds_sync();
-        if (a.last_cond && Sp >= 2) {  // P[::k] + conditional last sample (spline_opt.py:802-805)
+        if (last_cond && Sp >= 2) {  // P[::k] + conditional last sample (spline_opt.py:802-805)
             const int sa = sample_of(a, Sp - 2), sb = S - 1;
-            bool close = mp_abs(P0[sa] - P0[sb]) <= T(1e-8) + T(1e-5) * mp_abs(P0[sb]);
-            close = close && (mp_abs(P1[sa] - P1[sb]) <= T(1e-8) + T(1e-5) * mp_abs(P1[sb]));
-            close = close && (mp_abs(P2[sa] - P2[sb]) <= T(1e-8) + T(1e-5) * mp_abs(P2[sb]));
+            bool close = mp_abs(RF(sa, kP0) - RF(sb, kP0)) <= T(1e-8) + T(1e-5) * mp_abs(RF(sb, kP0));
+            close = close && (mp_abs(RF(sa, kP1) - RF(sb, kP1)) <= T(1e-8) + T(1e-5) * mp_abs(RF(sb, kP1)));
+            close = close && (mp_abs(RF(sa, kP2) - RF(sb, kP2)) <= T(1e-8) + T(1e-5) * mp_abs(RF(sb, kP2)));
             if (close) Sp -= 1;
         }
 
+        }
         MP_PHASE(3);  // clearance profile
+        MP_ARGS_REFRESH();
+        {
+        MP_LOCALS;
         // ---- clearance terms (and d cost / d d_k) ----
-        T t_safe = T(0), t_pref = T(0), t_reb = T(0), t_gc = T(0), t_gt = T(0), t_ac = T(0), t_acol = T(0);
-        T mc = Lim<T>::inf();
         for (int k = lane; k < Sp; k += 64) {
-            const T d = Dd[k];
+            const T d = RF(k, kD);
             mc = d < mc ? d : mc;
             T gd = T(0);
             if (mask & (1u << 3)) {
-                T e = npmax0(a.req - d);
+                T e = npmax0(req - d);
                 t_safe += e * e;
-                gd -= a.w[3] * T(2) * e;
+                gd -= w[3] * T(2) * e;
             }
-            if ((mask & (1u << 4)) && a.use_pref && k < a.keep_n) {
-                T e = npmax0(a.pref - d);
+            if ((mask & (1u << 4)) && use_pref && k < keep_n) {
+                T e = npmax0(pref - d);
                 t_pref += e * e;
-                gd -= a.w[4] * T(2) * e;
+                gd -= w[4] * T(2) * e;
             }
             if (mask & (1u << 5)) {
-                if (k >= a.tail_start && k + 1 < Sp) {
-                    T e = npmax0(Dd[k + 1] - d);
+                if (k >= tail_start && k + 1 < Sp) {
+                    T e = npmax0(RF(k + 1, kD) - d);
                     t_reb += e * e;
-                    gd -= a.w[5] * T(2) * e;
+                    gd -= w[5] * T(2) * e;
                 }
-                if (k - 1 >= a.tail_start && k - 1 >= 0) {
-                    T e = npmax0(d - Dd[k - 1]);
-                    gd += a.w[5] * T(2) * e;
+                if (k - 1 >= tail_start && k - 1 >= 0) {
+                    T e = npmax0(d - RF(k - 1, kD));
+                    gd += w[5] * T(2) * e;
                 }
             }
             if (k == Sp - 1) {
                 if (mask & (1u << 6)) {
-                    T e = d - a.pref;
+                    T e = d - pref;
                     e = e > T(0) ? e : T(0);
                     t_gc = e * e;
-                    gd += a.w[6] * T(2) * e;
+                    gd += w[6] * T(2) * e;
                 }
-                if ((mask & (1u << 7)) && a.use_goal_target) {
-                    T e = d - a.goal_tgt;
+                if ((mask & (1u << 7)) && use_goal_target) {
+                    T e = d - goal_tgt;
                     t_gt = e * e;
-                    gd += a.w[7] * T(2) * e;
+                    gd += w[7] * T(2) * e;
                 }
             }
-            if (a.amask[k]) {
+            if (amask[k]) {
                 if (mask & (1u << 8)) {
-                    T e = npmax0(a.appr_tgt - d);
+                    T e = npmax0(appr_tgt - d);
                     t_ac += e * e;
-                    gd -= a.w[8] * T(2) * e;
+                    gd -= w[8] * T(2) * e;
                 }
                 if (mask & (1u << 9)) {
                     T e = npmax0(-d);
                     t_acol += e * e;
-                    gd -= a.w[9] * T(2) * e;
+                    gd -= w[9] * T(2) * e;
                 }
             }
-            if (GRAD) GD[k] = gd;
+            if (GRAD) GDa[k] = gd;
         }
 
+        }
         MP_PHASE(4);  // clearance terms
+        MP_ARGS_REFRESH();
+        {
+        MP_LOCALS;
         // ---- small closed-form terms, computed redundantly by every lane ----
-        T t_via = T(0), t_ydev = T(0), t_gn = T(0);
         if (mask & (1u << 10))
             for (int j = 0; j < nf; ++j)
                 for (int c3 = 0; c3 < 3; ++c3) {
@@ -610,11 +673,10 @@ __global__ void __launch_bounds__(256, (eval_min_waves<T, GRAD, ROT>())) eval_ke
                 t_ydev += e * e;
             }
         // goal approach alignment: v = P[S-1] - P[first] (telescoped sum of the tail diffs)
-        T gnx = T(0), gny = T(0), gnz = T(0);
-        int gn_first = S - a.goal_tail_n;
+        gn_first = S - goal_tail_n;
         gn_first = gn_first < 0 ? 0 : gn_first;
         if ((mask & (1u << 14)) && tk.has_normal && S >= 3 && gn_first < S - 1) {
-            T vx = P0[S - 1] - P0[gn_first], vy = P1[S - 1] - P1[gn_first], vz = P2[S - 1] - P2[gn_first];
+            T vx = RF(S - 1, kP0) - RF(gn_first, kP0), vy = RF(S - 1, kP1) - RF(gn_first, kP1), vz = RF(S - 1, kP2) - RF(gn_first, kP2);
             T n, inv_n;
             sqrt_rsqrt(vx * vx + vy * vy + vz * vz, n, inv_n);
             if (!(n < T(1e-12))) {
@@ -627,7 +689,7 @@ __global__ void __launch_bounds__(256, (eval_min_waves<T, GRAD, ROT>())) eval_ke
                     t_gn = e * e;
                     if (GRAD && c > T(-1) && c < T(1)) {
                         T us = ux * sx + uy * sy + uz * sz;
-                        T k = a.w[14] * T(-2) * e;
+                        T k = w[14] * T(-2) * e;
                         gnx = k * -(sx - ux * us) * inv_n;
                         gny = k * -(sy - uy * us) * inv_n;
                         gnz = k * -(sz - uz * us) * inv_n;
@@ -636,7 +698,11 @@ __global__ void __launch_bounds__(256, (eval_min_waves<T, GRAD, ROT>())) eval_ke
             }
         }
 
+        }
         MP_PHASE(5);  // closed-form terms
+        MP_ARGS_REFRESH();
+        {
+        MP_LOCALS;
         // ---- reductions over the wave and outputs ----
         T term[kNTerms];
         T jtot = T(0);
@@ -658,32 +724,32 @@ __global__ void __launch_bounds__(256, (eval_min_waves<T, GRAD, ROT>())) eval_ke
             term[14] = t_gn;
 #pragma unroll
             for (int i = 0; i < kNTerms; ++i)
-                if (mask & (1u << i)) jtot = (i == 0) ? a.w[i] * term[i] : jtot + a.w[i] * term[i];
+                if (mask & (1u << i)) jtot = (i == 0) ? w[i] * term[i] : jtot + w[i] * term[i];
         } else {
             // cost only: weight the per-lane partial sums first, one wave reduction instead of twelve
             T part = T(0);
-            if (mask & 1u) part += a.w[0] * t_len;
-            if ((mask & 2u) && S >= 3) part += (a.w[1] * du) * t_curv;
-            if ((mask & 4u) && S >= 3) part += a.w[2] * t_ys;
-            if (mask & (1u << 3)) part += a.w[3] * t_safe;
-            if (mask & (1u << 4)) part += a.w[4] * t_pref;
-            if (mask & (1u << 5)) part += a.w[5] * t_reb;
-            if (mask & (1u << 6)) part += a.w[6] * t_gc;
-            if (mask & (1u << 7)) part += a.w[7] * t_gt;
-            if (mask & (1u << 8)) part += a.w[8] * t_ac;
-            if (mask & (1u << 9)) part += a.w[9] * t_acol;
-            if (mask & (1u << 12)) part += a.w[12] * t_mono;
-            if (mask & (1u << 13)) part += a.w[13] * t_sched;
+            if (mask & 1u) part += w[0] * t_len;
+            if ((mask & 2u) && S >= 3) part += (w[1] * du) * t_curv;
+            if ((mask & 4u) && S >= 3) part += w[2] * t_ys;
+            if (mask & (1u << 3)) part += w[3] * t_safe;
+            if (mask & (1u << 4)) part += w[4] * t_pref;
+            if (mask & (1u << 5)) part += w[5] * t_reb;
+            if (mask & (1u << 6)) part += w[6] * t_gc;
+            if (mask & (1u << 7)) part += w[7] * t_gt;
+            if (mask & (1u << 8)) part += w[8] * t_ac;
+            if (mask & (1u << 9)) part += w[9] * t_acol;
+            if (mask & (1u << 12)) part += w[12] * t_mono;
+            if (mask & (1u << 13)) part += w[13] * t_sched;
             jtot = wave_sum(part);
-            if (mask & (1u << 10)) jtot += a.w[10] * t_via;
-            if (mask & (1u << 11)) jtot += a.w[11] * t_ydev;
-            if (mask & (1u << 14)) jtot += a.w[14] * t_gn;
+            if (mask & (1u << 10)) jtot += w[10] * t_via;
+            if (mask & (1u << 11)) jtot += w[11] * t_ydev;
+            if (mask & (1u << 14)) jtot += w[14] * t_gn;
         }
         mc = wave_min(mc);
         if (lane == 0) {
             a.cost[cand] = jtot;
             if (a.minc) a.minc[cand] = mc;
-            if (a.flags) a.flags[cand] = (uint8_t)((mc < T(0) ? 1u : 0u) | (mc >= a.req ? 2u : 0u));
+            if (a.flags) a.flags[cand] = (uint8_t)((mc < T(0) ? 1u : 0u) | (mc >= req ? 2u : 0u));
         }
         if (a.terms && lane < kNTerms) {
             T v = T(0);
@@ -692,33 +758,14 @@ __global__ void __launch_bounds__(256, (eval_min_waves<T, GRAD, ROT>())) eval_ke
             a.terms[cand * kNTerms + lane] = v;
         }
 
+        }
         if (GRAD) {
             MP_PHASE(6);  // reductions + outputs
-            // (1) clearance chain: scatter d cost/d d_k * d d_k/d(P,yaw) to the sample it came from
             wave_lds_sync();
-            const T DEG2RAD = T(0.017453292519943295);
-            for (int k = lane; k < Sp; k += 64) {
-                const T gd = GD[k];
-                const int arg = ARG[k];
-                if (gd != T(0) && arg >= 0) {
-                    const int s = sample_of(a, k);
-                    const BoxRec<T> bx = boxes[arg];
-                    if (MODEL == 1) {
-                        T g0, g1, g2, g3;
-                        if (ROT == 2 && box_is_tilted(bx))
-                            tilt_grad(P0[s], P1[s], P2[s], CC[k], SS[k], a.ax, a.ay, a.az, bx, a.tilt, g0, g1, g2, g3);
-                        else
-                            pair_grad(P0[s], P1[s], P2[s], CC[k], SS[k], a.ax, a.ay, a.az, bx, ROT != 0, g0, g1, g2, g3);
-                        G0[s] = gd * g0; G1[s] = gd * g1; G2[s] = gd * g2;
-                        GY[s] = gd * g3 * DEG2RAD;
-                    } else {
-                        T g0, g1, g2;
-                        point_grad(P0[s], P1[s], P2[s], bx, ROT != 0, ROT == 2 ? a.tilt : nullptr, g0, g1, g2);
-                        G0[s] = gd * g0; G1[s] = gd * g1; G2[s] = gd * g2;
-                    }
-                }
-            }
             MP_PHASE(7);  // grad: clearance chain
+            MP_ARGS_REFRESH();
+            {
+            MP_LOCALS;
             // (2) curvature: T1 = A1 + G^T A2 (kept in D1*).  (G^T v)[s] = cm v[s-1] + c0 v[s] + cp v[s+1]
             // with the transposed np.gradient coefficients of row s (ends one-sided, inside central).
             const bool curv = (mask & 2u) && S >= 3;
@@ -728,25 +775,54 @@ __global__ void __launch_bounds__(256, (eval_min_waves<T, GRAD, ROT>())) eval_ke
                     const T cp = s == S - 2 ? -inv_du : ((s <= S - 3) ? -inv_h2 : T(0));
                     const T c0 = s == 0 ? -inv_du : (s == S - 1 ? inv_du : T(0));
                     const int lo = s == 0 ? 0 : s - 1, hi = s == S - 1 ? s : s + 1;
-                    D1x[s] = A1x[s] + (cm * A2x[lo] + c0 * A2x[s] + cp * A2x[hi]);
-                    D1y[s] = A1y[s] + (cm * A2y[lo] + c0 * A2y[s] + cp * A2y[hi]);
-                    D1z[s] = A1z[s] + (cm * A2z[lo] + c0 * A2z[s] + cp * A2z[hi]);
+                    RF(s, kD1x) = RF(s, kA1x) + (cm * RF(lo, kA2x) + c0 * RF(s, kA2x) + cp * RF(hi, kA2x));
+                    RF(s, kD1y) = RF(s, kA1y) + (cm * RF(lo, kA2y) + c0 * RF(s, kA2y) + cp * RF(hi, kA2y));
+                    RF(s, kD1z) = RF(s, kA1z) + (cm * RF(lo, kA2z) + c0 * RF(s, kA2z) + cp * RF(hi, kA2z));
                 }
             }
             wave_lds_sync();
+            }
             MP_PHASE(8);  // grad: curvature transpose
+            MP_ARGS_REFRESH();
+            {
+            MP_LOCALS;
+            const bool curv = (mask & 2u) && S >= 3;
+            const T y0 = tk.yaw_ctrl[0], y1 = tk.yaw_ctrl[Cy - 1];
             // (3) gather every contribution to gP[s], gyaw[s]
             for (int s = lane; s < S; s += 64) {
-                T gx = G0[s], gy = G1[s], gz = G2[s], gw = GY[s];
-                const T px = P0[s], py = P1[s], pz = P2[s], yw = YW[s];
-                if (mask & 1u) {  // SEGW[i] = w_len / |P[i+1] - P[i]| from the forward pass
+                T gx = T(0), gy = T(0), gz = T(0), gw = T(0);
+                {   // clearance chain: d cost/d d_k * d d_k/d(P, yaw) of the collision sample taken at this spline sample
+                    const int k = a.idx_identity ? s : a.inv_idx[s];
+                    if (k >= 0 && k < Sp) {
+                        const T gd = GDa[k];
+                        const int arg = ARG[k];
+                        if (gd != T(0) && arg >= 0) {
+                            const BoxRec<T> bx = boxes[arg];
+                            if (MODEL == 1) {
+                                T g0, g1, g2, g3;
+                                if (ROT == 2 && box_is_tilted(bx))
+                                    tilt_grad(RF(s, kP0), RF(s, kP1), RF(s, kP2), RF(k, kCC), RF(k, kSS), a.ax, a.ay, a.az, bx, a.tilt, g0, g1, g2, g3);
+                                else
+                                    pair_grad(RF(s, kP0), RF(s, kP1), RF(s, kP2), RF(k, kCC), RF(k, kSS), a.ax, a.ay, a.az, bx, ROT != 0, g0, g1, g2, g3);
+                                gx = gd * g0; gy = gd * g1; gz = gd * g2;
+                                gw = gd * g3 * T(0.017453292519943295);
+                            } else {
+                                T g0, g1, g2;
+                                point_grad(RF(s, kP0), RF(s, kP1), RF(s, kP2), bx, ROT != 0, ROT == 2 ? a.tilt : nullptr, g0, g1, g2);
+                                gx = gd * g0; gy = gd * g1; gz = gd * g2;
+                            }
+                        }
+                    }
+                }
+                const T px = RF(s, kP0), py = RF(s, kP1), pz = RF(s, kP2), yw = RF(s, kYW);
+                if (mask & 1u) {  // RF(i, kSEGW) = w_len / |P[i+1] - P[i]| from the forward pass
                     if (s >= 1) {
-                        const T k = SEGW[s - 1];
-                        gx += k * (px - P0[s - 1]); gy += k * (py - P1[s - 1]); gz += k * (pz - P2[s - 1]);
+                        const T k = RF(s - 1, kSEGW);
+                        gx += k * (px - RF(s - 1, kP0)); gy += k * (py - RF(s - 1, kP1)); gz += k * (pz - RF(s - 1, kP2));
                     }
                     if (s + 1 < S) {
-                        const T k = SEGW[s];
-                        gx -= k * (P0[s + 1] - px); gy -= k * (P1[s + 1] - py); gz -= k * (P2[s + 1] - pz);
+                        const T k = RF(s, kSEGW);
+                        gx -= k * (RF(s + 1, kP0) - px); gy -= k * (RF(s + 1, kP1) - py); gz -= k * (RF(s + 1, kP2) - pz);
                     }
                 }
                 if (curv) {
@@ -754,37 +830,41 @@ __global__ void __launch_bounds__(256, (eval_min_waves<T, GRAD, ROT>())) eval_ke
                     const T cp = s == S - 2 ? -inv_du : ((s <= S - 3) ? -inv_h2 : T(0));
                     const T c0 = s == 0 ? -inv_du : (s == S - 1 ? inv_du : T(0));
                     const int lo = s == 0 ? 0 : s - 1, hi = s == S - 1 ? s : s + 1;
-                    gx += cm * D1x[lo] + c0 * D1x[s] + cp * D1x[hi];
-                    gy += cm * D1y[lo] + c0 * D1y[s] + cp * D1y[hi];
-                    gz += cm * D1z[lo] + c0 * D1z[s] + cp * D1z[hi];
+                    gx += cm * RF(lo, kD1x) + c0 * RF(s, kD1x) + cp * RF(hi, kD1x);
+                    gy += cm * RF(lo, kD1y) + c0 * RF(s, kD1y) + cp * RF(hi, kD1y);
+                    gz += cm * RF(lo, kD1z) + c0 * RF(s, kD1z) + cp * RF(hi, kD1z);
                 }
                 if (s == S - 1) { gx += gnx; gy += gny; gz += gnz; }
                 if (s == gn_first) { gx -= gnx; gy -= gny; gz -= gnz; }
                 if ((mask & 4u) && S >= 3) {  // yaw smoothness: e_i = y_i - 2 y_{i+1} + y_{i+2}
-                    const T k2 = a.w[2] * T(2);
-                    if (s + 2 < S) gw += k2 * (yw - T(2) * YW[s + 1] + YW[s + 2]);
-                    if (s >= 1 && s + 1 < S) gw -= T(2) * k2 * (YW[s - 1] - T(2) * yw + YW[s + 1]);
-                    if (s >= 2) gw += k2 * (YW[s - 2] - T(2) * YW[s - 1] + yw);
+                    const T k2 = w[2] * T(2);
+                    if (s + 2 < S) gw += k2 * (yw - T(2) * RF(s + 1, kYW) + RF(s + 2, kYW));
+                    if (s >= 1 && s + 1 < S) gw -= T(2) * k2 * (RF(s - 1, kYW) - T(2) * yw + RF(s + 1, kYW));
+                    if (s >= 2) gw += k2 * (RF(s - 2, kYW) - T(2) * RF(s - 1, kYW) + yw);
                 }
                 if (mask & (1u << 12)) {
                     const T sg = tk.yaw_inc ? T(-1) : T(1);
                     if (s >= 1) {
-                        T dy = yw - YW[s - 1];
-                        gw += a.w[12] * T(2) * npmax0(tk.yaw_inc ? -dy : dy) * sg;
+                        T dy = yw - RF(s - 1, kYW);
+                        gw += w[12] * T(2) * npmax0(tk.yaw_inc ? -dy : dy) * sg;
                     }
                     if (s + 1 < S) {
-                        T dy = YW[s + 1] - yw;
-                        gw -= a.w[12] * T(2) * npmax0(tk.yaw_inc ? -dy : dy) * sg;
+                        T dy = RF(s + 1, kYW) - yw;
+                        gw -= w[12] * T(2) * npmax0(tk.yaw_inc ? -dy : dy) * sg;
                     }
                 }
                 if (mask & (1u << 13)) {
-                    T target = y0 + (y1 - y0) * a.tsched[s];
-                    gw += a.w[13] * T(2) * (yw - target);
+                    T target = y0 + (y1 - y0) * tsched[s];
+                    gw += w[13] * T(2) * (yw - target);
                 }
-                A1x[s] = gx; A1y[s] = gy; A1z[s] = gz; A2x[s] = gw;
+                RF(s, kA1x) = gx; RF(s, kA1y) = gy; RF(s, kA1z) = gz; RF(s, kA2x) = gw;
             }
             wave_lds_sync();
+            }
             MP_PHASE(9);  // grad: gather
+            MP_ARGS_REFRESH();
+            {
+            MP_LOCALS;
             // (4) x-gradient: M^T g.  Eight outputs per pass: lane = (output o = lane / 8, sample group g = lane % 8),
             // every lane sums its output over the samples s = g, g + 8, ... and three DPP steps add the eight groups
             // (instead of one full wave reduction per output with all lanes on the same output).
@@ -797,8 +877,8 @@ __global__ void __launch_bounds__(256, (eval_min_waves<T, GRAD, ROT>())) eval_ke
                     const bool is_pos = o < 3 * nf;
                     const int jj = is_pos ? o / 3 : o - 3 * nf;
                     const int comp = is_pos ? o - 3 * jj : 0;
-                    const T *V = is_pos ? A1x + comp * S : A2x;
-                    const T *Mc = is_pos ? a.M + ff + jj : a.My + 1 + jj;
+                    const T *V = REC + (is_pos ? (int)kA1x + comp : (int)kA2x);
+                    const T *Mc = is_pos ? M + ff + jj : My + 1 + jj;
                     const int ld = is_pos ? C : Cy;
                     // eight (M, g) pairs fetched per trip, then the same in-order fma chain (a one-at-a-time loop
                     // waits for every load in turn)
@@ -809,7 +889,7 @@ __global__ void __launch_bounds__(256, (eval_min_waves<T, GRAD, ROT>())) eval_ke
                             const int sidx = b0 + 8 * u;
                             const int sc = sidx < S ? sidx : S - 1;
                             mv[u] = Mc[(size_t)sc * ld];
-                            gv[u] = sidx < S ? V[sc] : T(0);
+                            gv[u] = sidx < S ? V[sc * NREC] : T(0);
                         }
 #pragma unroll
                         for (int u = 0; u < 8; ++u) acc = mp_fma(mv[u], gv[u], acc);
@@ -823,12 +903,13 @@ __global__ void __launch_bounds__(256, (eval_min_waves<T, GRAD, ROT>())) eval_ke
                     const int jj = is_pos ? o / 3 : o - 3 * nf;
                     const int comp = is_pos ? o - 3 * jj : 0;
                     if (is_pos) {
-                        if (mask & (1u << 10)) acc += a.w[10] * T(2) * (W[4 * (ff + jj) + comp] - tk.ctrl[ff + jj][comp]);
+                        if (mask & (1u << 10)) acc += w[10] * T(2) * (W[4 * (ff + jj) + comp] - tk.ctrl[ff + jj][comp]);
                     } else {
-                        if (mask & (1u << 11)) acc += a.w[11] * T(2) * (W[4 * (1 + jj) + 3] - tk.yaw_ctrl[1 + jj]);
+                        if (mask & (1u << 11)) acc += w[11] * T(2) * (W[4 * (1 + jj) + 3] - tk.yaw_ctrl[1 + jj]);
                     }
                     gout[o] = acc;
                 }
+            }
             }
         }
         MP_PHASE(10);  // grad: M^T g (or, cost only: reductions + outputs)
@@ -836,6 +917,10 @@ __global__ void __launch_bounds__(256, (eval_min_waves<T, GRAD, ROT>())) eval_ke
     }
     MP_PHASE_FLUSH;
 }
+#undef RF
+#undef a
+#undef MP_ARGS_REFRESH
+#undef MP_LOCALS
 
 // ---- split mode: the clearance profile on its own, one wave per (candidate, 64-sample chunk) --------------
 // With many samples per trajectory the LDS slice of eval_kernel leaves room for very few waves per CU, while
@@ -843,7 +928,7 @@ __global__ void __launch_bounds__(256, (eval_min_waves<T, GRAD, ROT>())) eval_ke
 // recomputes the chunk's spline samples with the same fma chain (same bits) and writes d and the deciding box.
 __host__ __device__ inline int clearance_lds_bytes_per_wave(int e)
 {
-    return (64 + 6 * 64) * e + 8 * 64 + 4 * 64 + 4 * 128;   // W | P0 P1 P2 YW CC SS | MINKEY | ARG | QUEUE
+    return (64 + kChunkRec * 64) * e + 8 * 64 + 4 * 64 + 4 * 128;   // W | REC[64][7] | MINKEY | ARG | QUEUE
 }
 
 template <typename T, int ROT>
@@ -857,8 +942,8 @@ __global__ void __launch_bounds__(256) clearance_kernel(const EvalArgs<T> a)
     const int D = 3 * nf + nyf;
     unsigned char *slice = smem_raw + (size_t)wib * clearance_lds_bytes_per_wave((int)sizeof(T));
     T *W = reinterpret_cast<T *>(slice);
-    T *P0 = W + 64, *P1 = P0 + 64, *P2 = P1 + 64, *YW = P2 + 64, *CC = YW + 64, *SS = CC + 64;
-    unsigned long long *MINKEY = reinterpret_cast<unsigned long long *>(SS + 64);
+    T *REC = W + 64;
+    unsigned long long *MINKEY = reinterpret_cast<unsigned long long *>(REC + kChunkRec * 64);
     int *ARG = reinterpret_cast<int *>(MINKEY + 64);
     unsigned int *QUEUE = reinterpret_cast<unsigned int *>(ARG + 64);
     const int chunks = (a.Sp + 63) >> 6;
@@ -903,10 +988,12 @@ __global__ void __launch_bounds__(256) clearance_kernel(const EvalArgs<T> a)
             const int s = sample_of(a, k);
             T px, py, pz, yw;
             spline_sample(a.M + (size_t)s * C, a.My + (size_t)s * Cy, C, Cy, W, px, py, pz, yw);
-            P0[lane] = px; P1[lane] = py; P2[lane] = pz; YW[lane] = yw;
+            T *r = REC + lane * kChunkRec;
+            r[kP0] = px; r[kP1] = py; r[kP2] = pz; r[kYW] = yw;
         }
         wave_lds_sync();
-        clearance_chunk<T, ROT, true, true>(a, boxes, boxes32, a.pairs + __builtin_amdgcn_readfirstlane(tk.spair_begin), groups, ngroups, n_wide, lane, k0, a.Sp, P0, P1, P2, YW, CC, SS, MINKEY, ARG, QUEUE);
+        clearance_chunk<T, ROT, true, true, kChunkRec>(a, boxes, boxes32, a.pairs + __builtin_amdgcn_readfirstlane(tk.spair_begin), groups, ngroups,
+                                                       n_wide, lane, k0, a.Sp, REC, MINKEY, ARG, QUEUE);
         if (k < a.Sp) {
             a.pre_d[cand * a.Sp + k] = key_to_distance<T>(MINKEY[lane]);
             a.pre_arg[cand * a.Sp + k] = ARG[lane];

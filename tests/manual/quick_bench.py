@@ -16,7 +16,10 @@ def check(prob, n, dtype):
     ok = np.array_equal(o["dist"], r["dist"]) and np.array_equal(o["flags"], r["flags"]) and np.array_equal(o["min_clear"], r["min_clear"])
     ce = np.max(np.abs(o["cost"].astype(float) - r["cost"].astype(float)) / np.abs(r["cost"].astype(float)))
     ge = np.max(np.abs(o["grad"].astype(float) - r["grad"].astype(float)) / (np.abs(r["grad"].astype(float)).max(axis=1, keepdims=True)))
+    o2 = ctx.eval(X, want_grad=True, want_terms=False)      # the launch the benchmarks time
+    ok = ok and np.array_equal(o2["grad"], o["grad"]) and np.array_equal(o2["flags"], o["flags"])
     print(f"  parity {np.dtype(dtype).name} S={prob.n_samples} B={prob.boxes.shape[0]}: exact={ok} cost_err={ce:.2e} grad_err={ge:.2e}")
+    assert ok and ce < 1e-4 and ge < 2e-3
     ctx.close()
 
 def bench(prob, n, dtype, grad, steps=10):

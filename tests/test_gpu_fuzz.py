@@ -72,6 +72,9 @@ def test_random_configuration_matches_oracle(seed, oracle_lib):
     out2 = ctx.eval(Xd, want_grad=False, want_terms=False)
     np.testing.assert_array_equal(out2["flags"], ref["flags"])
     np.testing.assert_array_equal(out2["min_clear"], ref["min_clear"])
+    out3 = ctx.eval(Xd, want_grad=True, want_terms=False)      # the launch DeviceBatch makes: no term breakdown
+    np.testing.assert_array_equal(out3["grad"], out["grad"])
+    np.testing.assert_array_equal(out3["flags"], ref["flags"])
     ctx.close()
 
 
@@ -121,18 +124,14 @@ def test_maximum_sizes(S, oracle_lib):
         try:
             ctx = native.Context(0)
             ctx.set_problem(prob)
-            if S <= 800:
-                out = ctx.eval(X, want_grad=True, want_dist=True)
-                _compare(out, ref, np.float64)
-            else:
-                # a gradient launch keeps 22 arrays of S elements per wave in LDS: beyond ~860 samples (fp64) that
-                # exceeds the CU's 160 KB and is refused loudly; the cost-only launch (10 arrays) still fits
-                with pytest.raises(native.NativeError, match="LDS per wave"):
-                    ctx.eval(X, want_grad=True)
-                out = ctx.eval(X, want_grad=False, want_terms=True, want_dist=True)
-                np.testing.assert_array_equal(out["dist"], ref["dist"])
-                np.testing.assert_array_equal(out["flags"], ref["flags"])
-                assert H.rel_err(out["cost"], ref["cost"]).max() < 1e-9
+            # a gradient launch keeps 17 fields per sample and wave in LDS: MP_MAX_SAMPLES = 1024 fp64 samples are a 153 KB
+            # slice, one wave per CU (round 1: 22 arrays, gradient launches beyond ~860 samples were refused)
+            out = ctx.eval(X, want_grad=True, want_dist=True)
+            _compare(out, ref, np.float64)
+            out = ctx.eval(X, want_grad=False, want_terms=True, want_dist=True)
+            np.testing.assert_array_equal(out["dist"], ref["dist"])
+            np.testing.assert_array_equal(out["flags"], ref["flags"])
+            assert H.rel_err(out["cost"], ref["cost"]).max() < 1e-9
             ctx.close()
         finally:
             os.environ.pop("MP_SPLIT_CLEARANCE", None)

@@ -66,6 +66,11 @@ def test_fp64_matches_oracle_and_golden(case, native, oracle_lib):
     out2 = ctx.eval(X, want_grad=False, want_terms=False)
     np.testing.assert_allclose(out2["cost"], out["cost"], rtol=1e-12)   # single weighted reduction vs per-term sums
     np.testing.assert_array_equal(out2["flags"], out["flags"])
+    # gradient launch without the term breakdown (what DeviceBatch / bench.py run): same gradient, same flags
+    out3 = ctx.eval(X, want_grad=True, want_terms=False)
+    np.testing.assert_array_equal(out3["grad"], out["grad"])
+    np.testing.assert_array_equal(out3["flags"], out["flags"])
+    np.testing.assert_allclose(out3["cost"], out["cost"], rtol=1e-12)
     ctx.close()
 
 
