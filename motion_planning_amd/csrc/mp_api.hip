@@ -517,6 +517,7 @@ int launch_eval(mp_ctx *ctx, long long n, const void *X, const int32_t *task_of,
     a.req = (T)c.required_clearance; a.pref = (T)c.preferred_clearance; a.appr_tgt = (T)c.approach_target;
     a.goal_tgt = (T)c.goal_clearance_target; a.radius = (T)c.point_radius;
     a.ax = (T)c.half_extents[0]; a.ay = (T)c.half_extents[1]; a.az = (T)c.half_extents[2];
+    a.trig = mp::trig_table<T>();
     a.du = T(1) / (T)(c.n_samples - 1); a.inv_du = T(1) / a.du; a.inv_h2 = T(1) / (T(2) * a.du);
     a.idx_safe = (const int *)ctx->d_idx.p; a.inv_idx = (const int *)ctx->d_inv.p; a.idx_identity = ctx->idx_identity; a.amask = (const uint8_t *)ctx->d_mask.p;
     a.M = (const T *)ctx->d_M.p; a.My = (const T *)ctx->d_My.p; a.tsched = (const T *)ctx->d_tsched.p;
@@ -1190,12 +1191,12 @@ int mp_box_sdf(mp_ctx *ctx, int64_t n, const void *pos, const void *yaw_deg, con
         hipLaunchKernelGGL(mp::box_sdf_kernel<double>, dim3(blocks), dim3(256), 0, ctx->stream, (long long)n,
                            (const double *)d_pos, (const double *)d_yaw,
                            (const mp::BoxRec<double> *)ctx->boxes.p + box_begin, box_count, hx, hy, hz,
-                           ctx->has_rot == 2 ? (const double *)ctx->tilt.p : nullptr, (double *)d_out);
+                           ctx->has_rot == 2 ? (const double *)ctx->tilt.p : nullptr, (double *)d_out, mp::trig_table<double>());
     else
         hipLaunchKernelGGL(mp::box_sdf_kernel<float>, dim3(blocks), dim3(256), 0, ctx->stream, (long long)n,
                            (const float *)d_pos, (const float *)d_yaw,
                            (const mp::BoxRec<float> *)ctx->boxes.p + box_begin, box_count, (float)hx, (float)hy,
-                           (float)hz, ctx->has_rot == 2 ? (const float *)ctx->tilt.p : nullptr, (float *)d_out);
+                           (float)hz, ctx->has_rot == 2 ? (const float *)ctx->tilt.p : nullptr, (float *)d_out, mp::trig_table<float>());
     HIP_TRY(ctx, hipGetLastError());
     if (mem == MP_MEM_HOST) {
         HIP_TRY(ctx, hipMemcpyAsync(out, d_out, (size_t)n * es, hipMemcpyDeviceToHost, ctx->stream));

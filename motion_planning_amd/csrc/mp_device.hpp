@@ -96,33 +96,46 @@ template <typename T> __device__ __forceinline__ T npmax0(T v) { return !(v <= T
 // Cody-Waite reduction by pi/2 (two fma steps) + degree-13/12 minimax kernels on
 // [-pi/4, pi/4]; the coefficient set is the classic fdlibm one.  Same op sequence as the
 // oracle's orc_sincos.
-template <typename T> __device__ __forceinline__ void sincos_reduced(T h, T &sn, T &cs)
+// The 16 constants travel as a table in the kernel arguments (TrigTab, filled by trig_table()): a 64-bit literal
+// cannot be an operand of a VALU instruction, so written as literals the compiler kept all of them in VGPR pairs for
+// the whole kernel (24+ vector registers of every fp64 kernel); read from the argument segment they are scalar
+// operands of the fma chain and live only while the chain runs.
+template <typename T> struct TrigTab {
+    T s[6], c[6];
+    T two_over_pi, pio2_hi, pio2_lo, deg2rad;
+};
+template <typename T> __host__ __device__ inline TrigTab<T> trig_table()
 {
-    const T TWO_OVER_PI = T(0.63661977236758134308);
-    const T PIO2_HI = Lim<T>::pio2_hi();
-    const T PIO2_LO = Lim<T>::pio2_lo();
-    const T S1 = T(-1.66666666666666324348e-01), S2 = T(8.33333333332248946124e-03),
-            S3 = T(-1.98412698298579493134e-04), S4 = T(2.75573137070700676789e-06),
-            S5 = T(-2.50507602534068634195e-08), S6 = T(1.58969099521155010221e-10);
-    const T C1 = T(4.16666666666666019037e-02), C2 = T(-1.38888888888741095749e-03),
-            C3 = T(2.48015872894767294178e-05), C4 = T(-2.75573143513906633035e-07),
-            C5 = T(2.08757232129817482790e-09), C6 = T(-1.13596475577881948265e-11);
-    T k = mp_rint(h * TWO_OVER_PI);
-    T r = mp_fma(-k, PIO2_HI, h);
-    r = mp_fma(-k, PIO2_LO, r);
+    TrigTab<T> t;
+    t.s[0] = T(-1.66666666666666324348e-01); t.s[1] = T(8.33333333332248946124e-03); t.s[2] = T(-1.98412698298579493134e-04);
+    t.s[3] = T(2.75573137070700676789e-06); t.s[4] = T(-2.50507602534068634195e-08); t.s[5] = T(1.58969099521155010221e-10);
+    t.c[0] = T(4.16666666666666019037e-02); t.c[1] = T(-1.38888888888741095749e-03); t.c[2] = T(2.48015872894767294178e-05);
+    t.c[3] = T(-2.75573143513906633035e-07); t.c[4] = T(2.08757232129817482790e-09); t.c[5] = T(-1.13596475577881948265e-11);
+    t.two_over_pi = T(0.63661977236758134308);
+    t.pio2_hi = sizeof(T) == 8 ? T(1.57079632679489655800e+00) : T(1.57079637050628662109e+00);
+    t.pio2_lo = sizeof(T) == 8 ? T(6.12323399573676603587e-17) : T(-4.37113882867379288655e-08);
+    t.deg2rad = T(0.017453292519943295);
+    return t;
+}
+
+template <typename T, typename TG> __device__ __forceinline__ void sincos_reduced(T h, const TG &g, T &sn, T &cs)
+{
+    T k = mp_rint(h * g.two_over_pi);
+    T r = mp_fma(-k, g.pio2_hi, h);
+    r = mp_fma(-k, g.pio2_lo, r);
     int q = (int)((long long)k) & 3;
     T z = r * r;
-    T ps = mp_fma(z, S6, S5);
-    ps = mp_fma(z, ps, S4);
-    ps = mp_fma(z, ps, S3);
-    ps = mp_fma(z, ps, S2);
-    ps = mp_fma(z, ps, S1);
+    T ps = mp_fma(z, g.s[5], g.s[4]);
+    ps = mp_fma(z, ps, g.s[3]);
+    ps = mp_fma(z, ps, g.s[2]);
+    ps = mp_fma(z, ps, g.s[1]);
+    ps = mp_fma(z, ps, g.s[0]);
     T sr = mp_fma(r * z, ps, r);
-    T pc = mp_fma(z, C6, C5);
-    pc = mp_fma(z, pc, C4);
-    pc = mp_fma(z, pc, C3);
-    pc = mp_fma(z, pc, C2);
-    pc = mp_fma(z, pc, C1);
+    T pc = mp_fma(z, g.c[5], g.c[4]);
+    pc = mp_fma(z, pc, g.c[3]);
+    pc = mp_fma(z, pc, g.c[2]);
+    pc = mp_fma(z, pc, g.c[1]);
+    pc = mp_fma(z, pc, g.c[0]);
     T cr = mp_fma(z * z, pc, mp_fma(T(-0.5), z, T(1.0)));
     T a = (q & 1) ? cr : sr;  // sin candidates
     T b = (q & 1) ? sr : cr;  // cos candidates
@@ -132,12 +145,11 @@ template <typename T> __device__ __forceinline__ void sincos_reduced(T h, T &sn,
 
 // yaw in degrees -> (cos, sin) composed like yaw_deg_to_quat + quat_to_rot
 // (geom/spline_opt.py:37-40, geom/utils.py:3-14).
-template <typename T> __device__ __forceinline__ void yaw_rot(T yaw_deg, T &c, T &s)
+template <typename T, typename TG> __device__ __forceinline__ void yaw_rot(T yaw_deg, const TG &g, T &c, T &s)
 {
-    const T DEG2RAD = T(0.017453292519943295);
-    T h = T(0.5) * (yaw_deg * DEG2RAD);
+    T h = T(0.5) * (yaw_deg * g.deg2rad);
     T zq, wq;
-    sincos_reduced(h, zq, wq);
+    sincos_reduced(h, g, zq, wq);
     c = T(1.0) - T(2.0) * (zq * zq);
     s = T(2.0) * (wq * zq);
 }

@@ -14,7 +14,7 @@ namespace mp {
 #define MP_MIN_WAVES 3
 #endif
 #ifndef MP_GRAD64_WAVES
-#define MP_GRAD64_WAVES MP_MIN_WAVES   // waves per SIMD the fp64 gradient kernels are register-budgeted for
+#define MP_GRAD64_WAVES 4   // waves per SIMD the fp64 gradient kernels are register-budgeted for
 #endif
 // Investigation builds only (tools/clearance_stats.py, tools/phase_clock.py build them into build_ab/):
 //   -DMP_STATS   work counters of the clearance phase (contended atomics: timings of such a build mean nothing)
@@ -61,6 +61,7 @@ template <typename T> struct EvalArgs {
     int n_tasks;
     T w[kNTerms];
     T req, pref, appr_tgt, goal_tgt, radius, ax, ay, az;
+    TrigTab<T> trig;        // constants of yaw_rot (mp_device.hpp)
     T du, inv_du, inv_h2;   // 1/(S-1), 1/du, 1/(2 du) in T arithmetic (host: the same correctly rounded divisions)
     const int *idx_safe;
     const int *inv_idx;   // [S] collision sample of each spline sample, -1: none (read only when !idx_identity)
@@ -178,7 +179,7 @@ __device__ __forceinline__ void clearance_chunk(const AT &a, const BoxRec<T> *bo
         const T *rs = REC + s * NREC;
         T *rk = REC + (LOCAL ? lane : k0 + lane) * NREC;
         T c, sn;
-        yaw_rot(rs[kYW], c, sn);
+        yaw_rot(rs[kYW], a.trig, c, sn);
         rk[kCC] = c; rk[kSS] = sn;
         MINKEY[lane] = key_init<T>();
         ARG[lane] = -1;
@@ -338,11 +339,8 @@ __device__ __forceinline__ void clearance_chunk(const AT &a, const BoxRec<T> *bo
 // ROT: 0 axis-aligned scene; 1 the scene holds yaw-rotated static boxes; 2 it also holds tilted ones (separate
 // instantiations keep the axis-aligned code as it was)
 // PRE: split mode, the clearance profile comes from clearance_kernel (box model only)
-// Waves per SIMD the register budget is sized for (measured, config 3): fp64 gradient kernels 3 (<= 168 VGPRs), fp64
-// cost-only kernels 4 (127 VGPRs; the CEM populations run on those), fp32 kernels 5 (<= 96 VGPRs).  A 4-wave build of the
-// fp64 gradient kernel (128 VGPRs, ~90 B of scratch per lane; the S = 64 slice lets 16 waves share a CU) measured 10 %
-// faster at config 3 in round 2 but returned wrong gradients on the GPU (ROCm 7.2; the 3-wave build of the same source
-// passes every parity test), so it is not built: DESIGN.md 9.
+// Waves per SIMD the register budget is sized for: fp64 kernels 4 (gradient 123 VGPRs, cost only 110; round 1 needed 168
+// for the gradient kernels: 3 waves), fp32 kernels 5 (<= 96 VGPRs).  None of the instances uses scratch memory.
 template <typename T, bool GRAD, int ROT = 0> constexpr int eval_min_waves()
 {
     return ROT == 2 ? 2   // the tilt routine is a real call: its registers count too
@@ -362,7 +360,9 @@ __global__ void __launch_bounds__(256, (eval_min_waves<T, GRAD, ROT>())) eval_ke
     KArgs *kargs = (KArgs *)__builtin_amdgcn_kernarg_segment_ptr();
     (void)a_by_value;
 #define a (*kargs)
-#define MP_ARGS_REFRESH() asm volatile("" : "+s"(kargs))
+    // `lane` goes through the same barrier: what the compiler derives from it (record addresses, masks) would otherwise
+    // be computed once and held in vector registers across the whole loop (163 VGPRs; recomputed per phase: 123)
+#define MP_ARGS_REFRESH() asm volatile("" : "+s"(kargs), "+v"(lane))
     // the scalar arguments a phase may use, read together at its start (one batch of scalar loads; what a phase does not
     // use is dropped by the compiler); `t` = the candidate's task
 #define MP_LOCALS                                                                                                          \
@@ -383,7 +383,7 @@ __global__ void __launch_bounds__(256, (eval_min_waves<T, GRAD, ROT>())) eval_ke
     (void)req; (void)pref; (void)appr_tgt; (void)goal_tgt; (void)w; (void)M; (void)My; (void)tsched; (void)amask;          \
     (void)tk; (void)boxes
     extern __shared__ __align__(16) unsigned char smem_raw[];
-    const int lane = threadIdx.x & 63;
+    int lane = threadIdx.x & 63;
     const int wib = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int wpb = (int)(blockDim.x >> 6);
     const int S_layout = a.S;   // inside the candidate loop every argument is re-read per phase (MP_LOCALS)
@@ -557,7 +557,7 @@ __global__ void __launch_bounds__(256, (eval_min_waves<T, GRAD, ROT>())) eval_ke
                 ARG[k] = a.pre_arg[cand * a.Sp + k];
                 if (GRAD) {
                     T c, sn;
-                    yaw_rot(RF(sample_of(a, k), kYW), c, sn);
+                    yaw_rot(RF(sample_of(a, k), kYW), a.trig, c, sn);
                     RF(k, kCC) = c; RF(k, kSS) = sn;
                 }
                 if (a.dist) a.dist[cand * a.Sp + k] = d;
@@ -805,7 +805,7 @@ __global__ void __launch_bounds__(256, (eval_min_waves<T, GRAD, ROT>())) eval_ke
                                 else
                                     pair_grad(RF(s, kP0), RF(s, kP1), RF(s, kP2), RF(k, kCC), RF(k, kSS), a.ax, a.ay, a.az, bx, ROT != 0, g0, g1, g2, g3);
                                 gx = gd * g0; gy = gd * g1; gz = gd * g2;
-                                gw = gd * g3 * T(0.017453292519943295);
+                                gw = gd * g3 * a.trig.deg2rad;
                             } else {
                                 T g0, g1, g2;
                                 point_grad(RF(s, kP0), RF(s, kP1), RF(s, kP2), bx, ROT != 0, ROT == 2 ? a.tilt : nullptr, g0, g1, g2);
@@ -1017,11 +1017,11 @@ __global__ void __launch_bounds__(256) point_sdf_kernel(long long n, const T *__
 template <typename T>
 __global__ void __launch_bounds__(256) box_sdf_kernel(long long n, const T *__restrict__ pos, const T *__restrict__ yaw,
                                                        const BoxRec<T> *__restrict__ boxes, int nb, T ax, T ay, T az,
-                                                       const T *__restrict__ tilt, T *__restrict__ out)
+                                                       const T *__restrict__ tilt, T *__restrict__ out, const TrigTab<T> trig)
 {
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
         T c, s;
-        yaw_rot(yaw[i], c, s);
+        yaw_rot(yaw[i], trig, c, s);
         Pose<T> ps;
         pose_setup(ps, pos[3 * i], pos[3 * i + 1], pos[3 * i + 2], c, s, ax, ay);
         int arg;

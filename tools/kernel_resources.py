@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Register / scratch / occupancy table of every kernel of the library (hipcc -S with the build flags), written to
-profiles/r01_kernel_resources.txt.  Runs on the CPU (cross-compile), ~1 min."""
+profiles/r02_kernel_resources.txt.  Runs on the CPU (cross-compile), ~1 min."""
 import re
 import subprocess
 import sys
@@ -39,5 +39,5 @@ out = ["# Resource usage of every kernel in libmp_hip.so (hipcc -S of motion_pla
 for (_, v), d in zip(rows, names):
     d = re.sub(r"\(.*$", "", d).replace("void ", "").replace("mp::", "")
     out.append(f"{d:58s} {v.get('v', -1):5d} {v.get('s', -1):5d} {v.get('sc', -1):9d} {v.get('o', -1):10d} {v.get('c', -1):7d}")
-(ROOT / "profiles" / "r01_kernel_resources.txt").write_text("\n".join(out) + "\n")
+(ROOT / "profiles" / "r02_kernel_resources.txt").write_text("\n".join(out) + "\n")
 print("\n".join(out))
