@@ -92,45 +92,22 @@ def _rate(db, X, steps):
     return X.shape[0] / (db.ctx.timer_stop() / steps * 1e-3)
 
 
-def workload_sweep(_native, problem, Xh, np_dtype, steps):
-    """The headline shape (65,536 x 64 samples x 50 boxes, cost + gradient) over the workload distribution: other scene
-    seeds, tighter / wider candidate clouds, and a mostly collision-free batch (what a late CEM generation or a refined
-    population looks like: small positive clearances, more pairs survive the culling bound).  Exact pairs per candidate
-    come from tools/workload_stats.py (-DMP_STATS build) when its summary is committed under profiles/."""
+def workload_cases(_native, problem, Xh, np_dtype):
+    """(name, problem, X) of the workload sweep: the headline shape over other scene seeds, tighter / wider candidate
+    clouds, and a mostly collision-free batch (what a late CEM generation or a refined population looks like: small
+    positive clearances, more pairs survive the culling bound)."""
     import torch
 
     from motion_planning_amd.batch import DeviceBatch, refine_gradient
     from motion_planning_amd.synthetic import synthetic_candidates, synthetic_problem
 
-    stats = {}
-    sfile = ROOT / "profiles" / "r02_workload_stats.json"
-    if sfile.exists():
-        try:
-            stats = json.loads(sfile.read_text())
-        except Exception:
-            stats = {}
-    rows = []
-
-    def measure(name, prob, Xn):
-        Xd = torch.from_numpy(np.ascontiguousarray(Xn, dtype=np_dtype)).cuda()
-        db = DeviceBatch(prob, Xd.shape[0], dtype=np_dtype, want_grad=True)
-        rate = _rate(db, Xd, steps)
-        torch.cuda.synchronize()
-        fl = db.flags.cpu().numpy()
-        row = {"case": name, "evals_per_s": rate, "colliding_fraction": float((fl & 1).mean()),
-               "feasible_fraction": float(((fl & 2) != 0).mean())}
-        if name in stats:
-            row["exact_pairs_per_candidate"] = stats[name].get("exact_pairs_per_candidate")
-        rows.append(row)
-        return db
-
     for seed in (1, 2, 3):
         p = synthetic_problem(_native.build_basis, N_BOXES, N_SAMPLES, seed=seed)
-        measure(f"scene_seed_{seed}", p, synthetic_candidates(p, N_CAND, seed=200 + seed)).close()
+        yield f"scene_seed_{seed}", p, synthetic_candidates(p, N_CAND, seed=200 + seed)
     rng = np.random.default_rng(300)
     eps = rng.normal(size=(N_CAND, problem.dim))
     for scale in (0.25, 1.0, 2.0):
-        measure(f"spread_{scale:g}_sigma", problem, problem.x0[None, :] + scale * eps * problem.sigma0[None, :]).close()
+        yield f"spread_{scale:g}_sigma", problem, problem.x0[None, :] + scale * eps * problem.sigma0[None, :]
     # a >= 90 % feasible batch: descend a small cloud with the analytic gradient, keep the feasible survivors, refill the
     # batch with slightly jittered copies of them
     db = DeviceBatch(problem, N_CAND, dtype=np_dtype, want_grad=True)
@@ -141,8 +118,36 @@ def workload_sweep(_native, problem, Xh, np_dtype, steps):
     if int(ok.sum()) >= 64:
         surv = ref["x"][ok].cpu().numpy().astype(np.float64)
         pick = rng.integers(0, surv.shape[0], size=N_CAND)
-        Xf = surv[pick] + 0.01 * rng.normal(size=(N_CAND, problem.dim)) * problem.sigma0[None, :]
-        measure("refined_mostly_feasible", problem, Xf).close()
+        yield "refined_mostly_feasible", problem, surv[pick] + 0.01 * rng.normal(size=(N_CAND, problem.dim)) * problem.sigma0[None, :]
+
+
+def workload_sweep(_native, problem, Xh, np_dtype, steps):
+    """Throughput of the headline shape (65,536 x 64 samples x 50 boxes, cost + gradient) over workload_cases().  Exact
+    pairs per candidate come from tools/workload_stats.py (-DMP_STATS build) when its summary is committed under profiles/."""
+    import torch
+
+    from motion_planning_amd.batch import DeviceBatch
+
+    stats = {}
+    sfile = ROOT / "profiles" / "r02_workload_stats.json"
+    if sfile.exists():
+        try:
+            stats = json.loads(sfile.read_text())
+        except Exception:
+            stats = {}
+    rows = []
+    for name, prob, Xn in workload_cases(_native, problem, Xh, np_dtype):
+        Xd = torch.from_numpy(np.ascontiguousarray(Xn, dtype=np_dtype)).cuda()
+        db = DeviceBatch(prob, Xd.shape[0], dtype=np_dtype, want_grad=True)
+        rate = _rate(db, Xd, steps)
+        torch.cuda.synchronize()
+        fl = db.flags.cpu().numpy()
+        row = {"case": name, "evals_per_s": rate, "colliding_fraction": float((fl & 1).mean()),
+               "feasible_fraction": float(((fl & 2) != 0).mean())}
+        if name in stats:
+            row["exact_pairs_per_candidate"] = stats[name].get("exact_pairs_per_candidate")
+        rows.append(row)
+        db.close()
     vals = sorted(r["evals_per_s"] for r in rows)
     return {"cases": rows, "min_evals_per_s": vals[0], "median_evals_per_s": vals[len(vals) // 2], "max_evals_per_s": vals[-1],
             "shape": "65,536 candidates x 64 samples x 50 boxes, fp64 cost + gradient, one MI355X"}
