@@ -193,34 +193,90 @@ def solve_scenarios_cem(problems: Sequence[PathProblem], restarts: int = 32, dev
     }
 
 
-def refine_gradient(db: DeviceBatch, X: torch.Tensor, iters: int = 20, step0: float = 0.05, shrink: float = 0.5,
-                    grow: float = 1.3, scale: Optional[torch.Tensor] = None) -> Dict[str, torch.Tensor]:
-    """Batched local refinement with the analytic gradient (the reference has no counterpart: its local
-    stage is the derivative-free Powell search, geom/spline_opt.py:339-344).
-
-    Per candidate: a normalised-gradient step with its own step length, accepted only if the cost drops
-    (otherwise the step shrinks) — monotone descent that tolerates the kinks of the sub-gradient.
+def refine_gradient(db: DeviceBatch, X: torch.Tensor, iters: int = 20, step0: float = 0.05,
+                    scale: Optional[torch.Tensor] = None, chunk: int = 2048, **_ignored) -> Dict[str, torch.Tensor]:
+    """Batched local refinement with the analytic gradient, device resident (the reference has no counterpart: its
+    local stage is the derivative-free Powell search, geom/spline_opt.py:339-344).  Same algorithm as
+    ``spline_opt._refine_with_gradient``, on tensors that stay in HBM: per iteration every candidate evaluates a fan of
+    trial points — line searches along the gradient and along a BFGS direction, multi-scale probes along every
+    coordinate, repeats of its last move — and moves to the best one if that lowers its cost (monotone).
     ``scale`` (D,) preconditions the mixed units of x (metres and degrees); default: the problem's sigma0.
-    Everything stays on the GPU; one ``mp_eval`` launch per iteration."""
+    One ``mp_eval`` launch per iteration and ``chunk`` candidates (a fan is ~110 trial points per candidate)."""
+    from .spline_opt import _COMPASS_LEVELS, _LINE_ALPHAS, _PATTERN, _QN_ALPHAS
+
     if db.grad is None:
         raise ValueError("DeviceBatch was created without want_grad")
-    x = X.clone()
-    out = db.evaluate(x)
-    cost, grad = out["cost"].clone(), out["grad"].clone()
-    minc, flags = out["min_clear"].clone(), out["flags"].clone()
-    step = torch.full_like(cost, float(step0))
+    dev, dt = X.device, X.dtype
     if scale is None:
-        scale = torch.as_tensor(db.problem.sigma0, dtype=x.dtype, device=x.device)
-    for _ in range(iters):
-        gs = grad * scale[None, :]
-        gnorm = gs.norm(dim=1, keepdim=True).clamp_min(1e-30)
-        trial = (x - step[:, None] * scale[None, :] * gs / gnorm).contiguous()
-        o = db.evaluate(trial)
-        better = o["cost"] < cost
-        x = torch.where(better[:, None], trial, x)
-        grad = torch.where(better[:, None], o["grad"], grad)
-        minc = torch.where(better, o["min_clear"], minc)
-        flags = torch.where(better, o["flags"], flags)
-        cost = torch.where(better, o["cost"], cost)
-        step = torch.where(better, step * grow, step * shrink)
-    return {"x": x, "cost": cost, "min_clear": minc, "flags": flags}
+        scale = torch.as_tensor(db.problem.sigma0, dtype=dt, device=dev)
+    n, D = X.shape
+    al = torch.tensor(_LINE_ALPHAS, dtype=dt, device=dev)
+    qa = torch.tensor(_QN_ALPHAS, dtype=dt, device=dev)
+    ga = torch.tensor(_PATTERN, dtype=dt, device=dev)
+    A = al.numel()
+    probes = torch.zeros(2 * D * len(_COMPASS_LEVELS), D, dtype=dt, device=dev)
+    row = 0
+    for level in _COMPASS_LEVELS:
+        for j in range(D):
+            probes[row, j], probes[row + 1, j] = level * scale[j], -level * scale[j]
+            row += 2
+    K = A + qa.numel() + probes.shape[0] + ga.numel()
+    chunk = max(1, min(int(chunk), db.capacity // K))
+    if chunk < 1 or db.capacity < K:
+        raise ValueError(f"DeviceBatch capacity {db.capacity} is below one fan of {K} trial points")
+    x = X.clone()
+    out = {"x": x, "cost": torch.empty(n, dtype=dt, device=dev), "min_clear": torch.empty(n, dtype=dt, device=dev),
+           "flags": torch.empty(n, dtype=torch.uint8, device=dev)}
+    for lo in range(0, n, chunk):
+        hi = min(n, lo + chunk)
+        R = hi - lo
+        xc = x[lo:hi]
+        o = db.evaluate(xc.contiguous())
+        cost, grad = o["cost"].clone(), o["grad"].clone()
+        minc, flags = o["min_clear"].clone(), o["flags"].clone()
+        step = torch.full((R,), float(step0), dtype=dt, device=dev)
+        last = torch.zeros(R, D, dtype=dt, device=dev)
+        Hinv = torch.zeros(R, D, D, dtype=dt, device=dev)
+        started = torch.zeros(R, dtype=torch.bool, device=dev)
+        eye = torch.eye(D, dtype=dt, device=dev)
+        rows = torch.arange(R, device=dev)
+        for _ in range(int(iters)):
+            gz = grad * scale[None, :]
+            unit = gz / gz.norm(dim=1, keepdim=True).clamp_min(1e-30)
+            dz = -torch.einsum("rij,rj->ri", Hinv, gz)
+            trials = torch.cat([
+                xc[:, None, :] - (step[:, None, None] * al[None, :, None]) * (scale[None, :] * unit)[:, None, :],
+                xc[:, None, :] + qa[None, :, None] * (dz * scale[None, :])[:, None, :],
+                xc[:, None, :] + probes[None, :, :],
+                xc[:, None, :] + ga[None, :, None] * last[:, None, :],
+            ], dim=1)
+            t = db.evaluate(trials.reshape(R * K, D).contiguous())
+            c2 = t["cost"].reshape(R, K)
+            c2 = torch.where(torch.isfinite(c2), c2, torch.full_like(c2, float("inf")))
+            j = torch.argmin(c2, dim=1)
+            best = c2[rows, j]
+            better = best < cost
+            pick = rows * K + j
+            new_x = torch.where(better[:, None], trials[rows, j], xc)
+            new_g = torch.where(better[:, None], t["grad"][pick], grad)
+            minc = torch.where(better, t["min_clear"][pick], minc)
+            flags = torch.where(better, t["flags"][pick], flags)
+            sv, yv = (new_x - xc) / scale[None, :], (new_g - grad) * scale[None, :]
+            sy = (sv * yv).sum(dim=1)
+            ok = better & (sy > 1e-12 * sv.norm(dim=1) * yv.norm(dim=1))
+            sy_safe = torch.where(ok, sy, torch.ones_like(sy))
+            first = ok & ~started
+            Hinv = torch.where(first[:, None, None], eye[None] * (sy_safe / (yv * yv).sum(dim=1).clamp_min(1e-300))[:, None, None], Hinv)
+            started = started | first
+            V = eye[None] - sv[:, :, None] * yv[:, None, :] / sy_safe[:, None, None]
+            Hnew = V @ Hinv @ V.transpose(1, 2) + sv[:, :, None] * sv[:, None, :] / sy_safe[:, None, None]
+            Hinv = torch.where(ok[:, None, None], Hnew, Hinv)
+            last = torch.where(better[:, None], new_x - xc, torch.zeros_like(xc))
+            xc, grad = new_x, new_g
+            cost = torch.where(better, best, cost)
+            on_line = better & (j < A)
+            grow = on_line & (al[j.clamp_max(A - 1)] >= 2.0)
+            step = torch.where(grow, step * 2.0, torch.where(on_line, step, step * 0.5)).clamp_min(1e-5)
+        x[lo:hi] = xc
+        out["cost"][lo:hi], out["min_clear"][lo:hi], out["flags"][lo:hi] = cost, minc, flags
+    return out

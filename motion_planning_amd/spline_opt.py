@@ -253,41 +253,124 @@ _HYBRID_CEM_DEFAULTS = dict(population_size=48, elite_frac=0.2, max_iter=60, tol
 _HYBRID_POWELL_DEFAULTS = dict(maxiter=80, xtol=1e-3, ftol=1e-3)
 
 
-_GRAD_DEFAULTS = dict(iters=40, restarts=16, jitter=0.05, step0=0.05, shrink=0.5, grow=1.3)
+_GRAD_DEFAULTS = dict(iters=40, n_starts=8, copies=2, jitter=0.05, step0=0.05)
+_LINE_ALPHAS = (0.125, 0.25, 0.5, 1.0, 2.0, 4.0, 8.0)        # gradient line search: multiples of the adaptive step
+_QN_ALPHAS = (0.03, 0.1, 0.3, 0.6, 1.0, 1.5, 2.5)            # quasi-Newton line search: multiples of the BFGS step
+_COMPASS_LEVELS = (0.003, 0.01, 0.03, 0.1, 0.3, 1.0)         # coordinate probes: +- level * sigma0_j
+_PATTERN = (1.0, 2.0)                                        # repeats of the last accepted move
 
 
-def _refine_with_gradient(value_and_grad: Callable, x: np.ndarray, sigma0: np.ndarray, iters: int = 40, restarts: int = 16,
-                          jitter: float = 0.05, step0: float = 0.05, shrink: float = 0.5, grow: float = 1.3,
-                          seed: Optional[int] = None) -> Dict:
-    """Batched local refinement with the analytic (sub)gradient — the stand-in for the reference's derivative-free
-    Powell stage (ref :338-359) that a batched evaluator makes cheap: ``restarts`` copies of ``x`` (the first exact,
-    the others jittered by ``jitter * sigma0``) descend together, one evaluator call per iteration.
+def _cem_optimize_multi(objective, x0, sigma0, seeds, population_size: int = 48, elite_frac: float = 0.2, max_iter: int = 60,
+                        tol: float = 1e-3, alpha: float = 0.7, min_sigma: float = 1e-3) -> List[Dict]:
+    """``len(seeds)`` independent runs of ``_cem_optimize`` (ref :222-277) advanced in lock-step: every generation the
+    populations of the runs still going are evaluated by ONE ``objective`` call.  Run k is, bit for bit, what
+    ``_cem_optimize(..., seed=seeds[k])`` returns (same generator, same draw order, same update); only the number of
+    evaluator calls changes — max over the runs instead of their sum."""
+    runs = []
+    for sd in seeds:
+        runs.append({"rng": np.random.default_rng(sd), "mean": np.asarray(x0, dtype=float).copy(),
+                     "spread": np.maximum(np.asarray(sigma0, dtype=float), min_sigma), "x": np.asarray(x0, dtype=float).copy(),
+                     "fun": float("inf"), "prev": float("inf"), "nit": 0, "done": False})
+    dim = runs[0]["mean"].size
+    n_elite = max(2, int(np.ceil(population_size * elite_frac)))
+    for _ in range(int(max_iter)):
+        live = [r for r in runs if not r["done"]]
+        if not live:
+            break
+        pops = []
+        for r in live:
+            r["nit"] += 1
+            pops.append(r["mean"][None, :] + r["rng"].normal(size=(population_size, dim)) * r["spread"][None, :])
+        values = np.asarray(objective(np.vstack(pops)), dtype=float).reshape(len(live), population_size)
+        for r, population, vals in zip(live, pops, values):
+            lead = int(np.argmin(vals))
+            if vals[lead] < r["fun"]:
+                r["fun"], r["x"] = float(vals[lead]), population[lead].copy()
+            chosen = population[np.argpartition(vals, n_elite - 1)[:n_elite]]
+            r["mean"] = alpha * r["mean"] + (1.0 - alpha) * np.mean(chosen, axis=0)
+            r["spread"] = np.maximum(alpha * r["spread"] + (1.0 - alpha) * (np.std(chosen, axis=0) + min_sigma), min_sigma)
+            if np.abs(r["prev"] - r["fun"]) < tol and float(np.max(r["spread"])) < 0.03:
+                r["done"] = True
+            r["prev"] = r["fun"]
+    return [{"x": r["x"], "fun": r["fun"], "nit": r["nit"], "success": True, "message": "CEM finished"} for r in runs]
 
-    Per copy: a step of its own length along the gradient normalised in sigma0 units (metres and degrees mix in x),
-    accepted only if the cost drops, otherwise the step shrinks — monotone descent that tolerates the kinks of the
-    sub-gradient.  ``value_and_grad(X) -> (cost (n,), grad (n, D))``."""
+
+def _refine_with_gradient(value_and_grad: Callable, x: np.ndarray, sigma0: np.ndarray, iters: int = 40, copies: int = 2,
+                          jitter: float = 0.05, step0: float = 0.05, seed: Optional[int] = None, **_ignored) -> Dict:
+    """Batched local refinement with the analytic (sub)gradient — the stand-in for the reference's derivative-free Powell
+    stage (ref :338-359) that a batched evaluator makes cheap.  ``x``: one start (D,) or several (R, D); every start is
+    refined ``copies`` times (the first copy exact, the others jittered by ``jitter * sigma0``), all of them together, ONE
+    evaluator call per iteration.
+
+    Per iteration and copy a fan of trial points is evaluated and the best one is taken if it lowers the cost:
+    a line search along the gradient (normalised in sigma0 units: metres and degrees mix in x) at seven multiples of an
+    adaptive step; the same along the BFGS quasi-Newton direction built from the accepted moves (follows curved valleys
+    that defeat the plain gradient); +-sigma0_j * level probes along every coordinate at six scales (the batched
+    counterpart of the bracketing line searches Powell runs along each direction: robust at the kinks of the
+    sub-gradient); and repeats of the last accepted move.  Monotone: a copy never gets worse.
+    ``value_and_grad(X) -> (cost (n,), grad (n, D))``."""
     rng = np.random.default_rng(seed)
-    x = np.asarray(x, dtype=float)
     scale = np.asarray(sigma0, dtype=float)
-    X = np.repeat(x[None, :], max(1, int(restarts)), axis=0)
-    X[1:] += jitter * scale[None, :] * rng.normal(size=X[1:].shape)
+    starts = np.atleast_2d(np.asarray(x, dtype=float))
+    D = starts.shape[1]
+    X = np.repeat(starts, max(1, int(copies)), axis=0)
+    extra = np.ones(X.shape[0], dtype=bool)
+    extra[:: max(1, int(copies))] = False
+    X[extra] += jitter * scale[None, :] * rng.normal(size=(int(extra.sum()), D))
+    R = X.shape[0]
     cost, grad = value_and_grad(X)
     cost, grad = np.array(cost, dtype=float), np.array(grad, dtype=float)
-    step = np.full(X.shape[0], float(step0))
-    n_eval = X.shape[0]
+    n_eval = R
+    al, qa, ga = np.asarray(_LINE_ALPHAS), np.asarray(_QN_ALPHAS), np.asarray(_PATTERN)
+    A = al.size
+    probes = np.zeros((2 * D * len(_COMPASS_LEVELS), D))
+    row = 0
+    for level in _COMPASS_LEVELS:
+        for j in range(D):
+            probes[row, j], probes[row + 1, j] = level * scale[j], -level * scale[j]
+            row += 2
+    step = np.full(R, float(step0))
+    last = np.zeros((R, D))
+    Hinv = np.zeros((R, D, D))          # inverse Hessian estimate in scaled coordinates z = x / sigma0; zero until the first update
+    rows = np.arange(R)
     for _ in range(int(iters)):
-        gs = grad * scale[None, :]
-        gnorm = np.maximum(np.linalg.norm(gs, axis=1, keepdims=True), 1e-30)
-        trial = X - step[:, None] * scale[None, :] * gs / gnorm
-        c2, g2 = value_and_grad(trial)
-        n_eval += X.shape[0]
-        better = np.asarray(c2) < cost
-        X = np.where(better[:, None], trial, X)
-        grad = np.where(better[:, None], g2, grad)
-        cost = np.where(better, c2, cost)
-        step = np.where(better, step * grow, step * shrink)
+        gz = grad * scale[None, :]
+        unit = gz / np.maximum(np.linalg.norm(gz, axis=1, keepdims=True), 1e-30)
+        dz = -np.einsum("rij,rj->ri", Hinv, gz)
+        trials = np.concatenate([
+            X[:, None, :] - (step[:, None, None] * al[None, :, None]) * (scale[None, :] * unit)[:, None, :],
+            X[:, None, :] + qa[None, :, None] * (dz * scale[None, :])[:, None, :],
+            X[:, None, :] + probes[None, :, :],
+            X[:, None, :] + ga[None, :, None] * last[:, None, :],
+        ], axis=1)
+        K = trials.shape[1]
+        c2, g2 = value_and_grad(trials.reshape(R * K, D))
+        n_eval += R * K
+        c2 = np.asarray(c2, dtype=float).reshape(R, K)
+        g2 = np.asarray(g2, dtype=float).reshape(R, K, D)
+        c2 = np.where(np.isfinite(c2), c2, np.inf)
+        j = np.argmin(c2, axis=1)
+        best = c2[rows, j]
+        better = best < cost
+        new_x = np.where(better[:, None], trials[rows, j], X)
+        new_g = np.where(better[:, None], g2[rows, j], grad)
+        # BFGS update of the accepted moves that satisfy the curvature condition
+        sv, yv = (new_x - X) / scale[None, :], (new_g - grad) * scale[None, :]
+        sy = np.sum(sv * yv, axis=1)
+        ok = better & (sy > 1e-12 * np.linalg.norm(sv, axis=1) * np.linalg.norm(yv, axis=1))
+        for r in np.nonzero(ok)[0]:
+            if not Hinv[r].any():
+                Hinv[r] = np.eye(D) * (sy[r] / float(yv[r] @ yv[r]))
+            V = np.eye(D) - np.outer(sv[r], yv[r]) / sy[r]
+            Hinv[r] = V @ Hinv[r] @ V.T + np.outer(sv[r], sv[r]) / sy[r]
+        last = np.where(better[:, None], new_x - X, 0.0)
+        X, grad = new_x, new_g
+        cost = np.where(better, best, cost)
+        on_line = better & (j < A)
+        grow = on_line & (al[np.minimum(j, A - 1)] >= 2.0)
+        step = np.maximum(np.where(grow, step * 2.0, np.where(on_line, step, step * 0.5)), 1e-5)
     i = int(np.argmin(cost))
-    return {"x": X[i].copy(), "fun": float(cost[i]), "nit": int(iters), "n_eval": int(n_eval)}
+    return {"x": X[i].copy(), "fun": float(cost[i]), "nit": int(iters), "n_eval": int(n_eval), "all_fun": cost.copy()}
 
 
 def _solve_optimizer(objective_single, x0, sigma0, method: str, options: Optional[Dict] = None,
@@ -328,13 +411,21 @@ def _solve_optimizer(objective_single, x0, sigma0, method: str, options: Optiona
                     cem[key] = val
                 if key in grad_opt:
                     grad_opt[key] = val
-        stage1 = _cem_optimize(objective_batch, x0=x0, sigma0=sigma0, **cem)
-        stage2 = _refine_with_gradient(value_and_grad, stage1["x"], sigma0, seed=cem.get("seed"), **grad_opt)
-        if stage2["fun"] <= float(stage1["fun"]):
+        if "restarts" in grad_opt:      # round-1 option name: total number of refined copies
+            grad_opt["copies"] = max(1, int(grad_opt.pop("restarts")) // max(1, int(grad_opt["n_starts"])))
+        # several CEM runs in lock-step (run 0 is the reference's seeded run), every run's best refined together
+        seed = cem.pop("seed")
+        n_starts = max(1, int(grad_opt.pop("n_starts")))
+        seeds = [seed if k == 0 else (None if seed is None else int(seed) + 1000 * k) for k in range(n_starts)]
+        stage1 = _cem_optimize_multi(objective_batch, x0, sigma0, seeds, **cem)
+        stage2 = _refine_with_gradient(value_and_grad, np.array([r["x"] for r in stage1]), sigma0, seed=seed, **grad_opt)
+        lead = min(stage1, key=lambda r: r["fun"])
+        nit1 = max(int(r["nit"]) for r in stage1)
+        if stage2["fun"] <= float(lead["fun"]):
             return {"x": stage2["x"], "success": True, "message": "Hybrid CEM+gradient: refined", "fun": stage2["fun"],
-                    "nit": int(stage1["nit"]) + int(stage2["nit"])}
-        return {"x": stage1["x"], "success": bool(stage1["success"]), "message": "Hybrid CEM+gradient: kept CEM result",
-                "nit": int(stage1["nit"]), "fun": float(stage1["fun"])}
+                    "nit": nit1 + int(stage2["nit"])}
+        return {"x": lead["x"], "success": True, "message": "Hybrid CEM+gradient: kept CEM result", "nit": nit1,
+                "fun": float(lead["fun"])}
 
     if name in {"CEM-POWELL", "HYBRID"}:
         cem, powell = dict(_HYBRID_CEM_DEFAULTS), dict(_HYBRID_POWELL_DEFAULTS)

@@ -474,16 +474,49 @@ def test_gradient_refinement_descends(native):
     from motion_planning_amd.synthetic import synthetic_candidates, synthetic_problem
 
     prob = synthetic_problem(native.build_basis, 50, 64, 0)
-    n = 4096
+    n = 1024
     X = torch.from_numpy(prob.x0 + 0.2 * prob.sigma0 * np.random.default_rng(2).normal(size=(n, prob.dim))).cuda()
-    db = DeviceBatch(prob, n, want_grad=True)
+    db = DeviceBatch(prob, 65536, want_grad=True)
     start = db.evaluate(X)["cost"].clone()
-    res = refine_gradient(db, X, iters=30)
+    res = refine_gradient(db, X, iters=15)
     assert bool((res["cost"] <= start).all())
     assert float((res["cost"] < 0.9 * start).double().mean()) > 0.5          # most candidates improve by > 10 %
     again = db.evaluate(res["x"].contiguous())
     assert torch.equal(again["cost"], res["cost"]) and torch.equal(again["flags"], res["flags"])
+    assert torch.equal(again["min_clear"], res["min_clear"])
     db.close()
+
+
+def test_cem_grad_matches_cem_powell_on_the_shipped_scenarios():
+    """'CEM-GRAD' (8 CEM runs in lock-step, then the batched gradient / quasi-Newton / compass refinement) against the
+    reference's CEM-POWELL hybrid (geom/spline_opt.py:313-359) on the seven shipped scenarios, BASE_CONFIG, same seed:
+    within 1 % of CEM-POWELL's cost everywhere (measured: -50 % ... +0.0 %; `step_04` is a kinked valley where Powell's
+    result depends on the seed, 6.07 ... 12.15), with at most 60 + 1 + 40 evaluator calls (CEM-POWELL: CEM + one call per
+    Powell evaluation, several hundred)."""
+    from motion_planning_amd import spline_opt as so
+    from motion_planning_amd.configs import BASE_CONFIG
+    from motion_planning_amd.scenarios import scenario_from_resolved
+
+    calls = {}
+
+    def counting(tag):
+        def factory(problem):
+            ev = so.NativeEvaluator(problem)
+            calls[tag] = ev
+            return ev
+        return factory
+
+    for name, raw in H.load_scenarios().items():
+        sc = scenario_from_resolved(raw)
+        common = dict(scene=sc.scene, start=sc.start, goal=sc.goal, moving_block_size=sc.moving_block_size,
+                      start_yaw_deg=sc.start_yaw_deg, goal_yaw_deg=sc.goal_yaw_deg,
+                      goal_approach_normals=np.asarray(sc.goal_normals, dtype=float), **BASE_CONFIG)
+        _, _, ip = so.optimize_bspline_path(method="CEM-POWELL", options={"seed": 3}, evaluator_factory=counting("p"), **common)
+        _, vg, ig = so.optimize_bspline_path(method="CEM-GRAD", options={"seed": 3}, evaluator_factory=counting("g"), **common)
+        assert ig["fun"] <= 1.01 * ip["fun"], (name, ig["fun"], ip["fun"])
+        assert calls["g"].n_calls <= 60 + 1 + 40 + 3, (name, calls["g"].n_calls)       # + the post-solve evaluations
+        assert calls["g"].n_calls < calls["p"].n_calls
+        assert np.isfinite(vg).all() and ig["message"].startswith("Hybrid CEM+gradient")
 
 
 def test_plain_c_caller(native, oracle_lib):

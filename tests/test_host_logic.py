@@ -192,6 +192,17 @@ def test_cem_grad_hybrid_extension(oracle_lib):
     assert i1["message"].startswith("Hybrid CEM+gradient")
     with pytest.raises(ValueError, match="CEM-GRAD"):
         so._solve_optimizer(lambda x: (float(np.sum(x * x)),), np.ones(3), np.ones(3), "CEM-GRAD")
+    # the lock-step multi-start CEM: every run is bitwise the single run with its seed (ref :222-277)
+    f = lambda X: np.sum((X - np.array([0.3, -0.2, 0.5, 1.0])) ** 2, axis=1) + 0.1 * np.sin(5.0 * X[:, 0])
+    n_calls = []
+    multi = so._cem_optimize_multi(lambda X: (n_calls.append(len(X)), f(X))[1], np.zeros(4), np.array([0.5, 0.5, 1.0, 0.2]), [7, None, 9],
+                                   population_size=24, elite_frac=0.25, max_iter=40, alpha=0.6)
+    for k, sd in ((0, 7), (2, 9)):
+        one = so._cem_optimize(f, np.zeros(4), np.array([0.5, 0.5, 1.0, 0.2]), population_size=24, elite_frac=0.25, max_iter=40,
+                               alpha=0.6, seed=sd)
+        np.testing.assert_array_equal(multi[k]["x"], one["x"])
+        assert multi[k]["fun"] == one["fun"] and multi[k]["nit"] == one["nit"]
+    assert len(n_calls) == max(r["nit"] for r in multi) and n_calls[0] == 3 * 24     # one call per generation for all runs
     # the refinement alone on a smooth bowl: converges to the minimum
     res = so._refine_with_gradient(lambda X: (np.sum((X - 2.0) ** 2, axis=1), 2.0 * (X - 2.0)), np.zeros(4), np.ones(4), iters=80,
                                    restarts=4, step0=0.5, seed=0)

@@ -1,40 +1,40 @@
+#!/usr/bin/env python3
+"""CEM-GRAD against CEM-POWELL on the seven shipped scenarios (BASE_CONFIG), three seeds: cost, evaluator calls, wall time.
+Writes profiles/r02_cem_grad_vs_powell.json (DESIGN.md 4b quotes it)."""
+import json
 import sys
+import time
 from pathlib import Path
+
 import numpy as np
-sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
-import torch
-from motion_planning_amd import _native
-from motion_planning_amd.batch import DeviceBatch, refine_gradient
-from motion_planning_amd.synthetic import synthetic_candidates, synthetic_problem
-prob = synthetic_problem(_native.build_basis, 50, 64, 0)
-n = 4096
-X = torch.from_numpy(prob.x0 + 0.2 * prob.sigma0 * np.random.default_rng(2).normal(size=(n, prob.dim))).cuda()
-db = DeviceBatch(prob, n, want_grad=True, want_terms=True)
-o = {k: v.clone() for k, v in db.evaluate(X).items()}
-print("start cost median", o["cost"].median().item(), "terms median", o["terms"].median(dim=0).values.cpu().numpy().round(3))
-print("weights", prob.weights)
-print("grad median abs", o["grad"].abs().median(dim=0).values.cpu().numpy())
-for it in (10, 30, 100):
-    r = refine_gradient(db, X, iters=it)
-    ratio = (r["cost"] / o["cost"])
-    print(it, "median ratio", ratio.median().item(), "min", ratio.min().item(), "frac<0.9", (ratio < 0.9).double().mean().item())
-print("---- trace")
-x = X.clone()
-out = db.evaluate(x)
-cost = out["cost"].clone(); grad = out["grad"].clone()
-scale = torch.as_tensor(prob.sigma0, dtype=x.dtype, device=x.device)
-step = torch.full_like(cost, 0.05)
-for it in range(40):
-    gs = grad * scale[None, :]
-    gnorm = gs.norm(dim=1, keepdim=True).clamp_min(1e-30)
-    trial = (x - step[:, None] * scale[None, :] * gs / gnorm).contiguous()
-    o2 = db.evaluate(trial)
-    better = o2["cost"] < cost
-    x = torch.where(better[:, None], trial, x)
-    grad = torch.where(better[:, None], o2["grad"], grad)
-    cost = torch.where(better, o2["cost"], cost)
-    step = torch.where(better, step * 1.3, step * 0.5)
-    if it % 4 == 0:
-        chk = db.evaluate(x.contiguous())["cost"]
-        print(it, "median cost", cost.median().item(), "accepted", better.double().mean().item(), "median step", step.median().item(),
-              "recheck max abs diff", (chk - cost).abs().max().item())
+
+ROOT = Path(__file__).resolve().parents[1]
+sys.path.insert(0, str(ROOT))
+from motion_planning_amd import spline_opt as so  # noqa: E402
+from motion_planning_amd.configs import BASE_CONFIG  # noqa: E402
+from motion_planning_amd.scenarios import scenario_from_resolved  # noqa: E402
+
+scen = json.loads((ROOT / "tests" / "golden" / "scenarios.json").read_text())["scenarios"]
+rows = []
+for name, raw in scen.items():
+    sc = scenario_from_resolved(raw)
+    common = dict(scene=sc.scene, start=sc.start, goal=sc.goal, moving_block_size=sc.moving_block_size, start_yaw_deg=sc.start_yaw_deg,
+                  goal_yaw_deg=sc.goal_yaw_deg, goal_approach_normals=np.asarray(sc.goal_normals, dtype=float), **BASE_CONFIG)
+    for seed in (3, 11, 5):
+        rec = {"scenario": name, "seed": seed}
+        for method in ("CEM-POWELL", "CEM-GRAD"):
+            held = {}
+
+            def factory(problem):
+                held["ev"] = so.NativeEvaluator(problem)
+                return held["ev"]
+
+            t0 = time.perf_counter()
+            _, _, info = so.optimize_bspline_path(method=method, options={"seed": seed}, evaluator_factory=factory, **common)
+            rec[method] = {"fun": info["fun"], "calls": held["ev"].n_calls, "evals": held["ev"].n_evals, "wall_ms": 1e3 * (time.perf_counter() - t0),
+                           "min_clearance": info["min_clearance"]}
+        rec["ratio"] = rec["CEM-GRAD"]["fun"] / rec["CEM-POWELL"]["fun"]
+        rows.append(rec)
+        print(f"{name:30s} seed {seed:2d}: CEM-POWELL {rec['CEM-POWELL']['fun']:12.4f} ({rec['CEM-POWELL']['calls']:4d} calls, {rec['CEM-POWELL']['wall_ms']:6.1f} ms)  "
+              f"CEM-GRAD {rec['CEM-GRAD']['fun']:12.4f} ({rec['CEM-GRAD']['calls']:4d} calls, {rec['CEM-GRAD']['wall_ms']:6.1f} ms)  {rec['ratio'] - 1:+.2%}", flush=True)
+(ROOT / "profiles" / "r02_cem_grad_vs_powell.json").write_text(json.dumps(rows, indent=1))
