@@ -31,8 +31,8 @@ extern "C" {
 /* ---- limits ------------------------------------------------------------------ */
 #define MP_MAX_CTRL 16    /* waypoints per spline (start + vias + goal)            */
 #define MP_MAX_SAMPLES 1024 /* n_samples_curve (the per-wave LDS slice of a gradient launch,
-                               17 values per sample, must fit the CU's 160 KB: 1024 fp64
-                               samples are 153 KB, one wave per CU)               */
+                               15 values + 4 bytes per sample, must fit the CU's 160 KB:
+                               1024 fp64 samples are 125 KB, one wave per CU)     */
 #define MP_NTERMS 15      /* cost terms, order of the weighted sum spline_opt.py:605-621 */
 
 /* ---- error codes ------------------------------------------------------------- */

@@ -135,37 +135,48 @@ __device__ __forceinline__ void spline_sample(const T *__restrict__ m, const T *
 }
 
 // LDS slice of one wave (bytes).  Layout (S = samples, e = sizeof(T)):
-//   W[64] | REC[S][NREC]  | MINKEY[S] (u64) | ARG[S] (int) | QUEUE[128] (u32)
+//   W[w_elems] | REC[S][NREC]  | MINKEY[S] (u64; not in fp64 gradient launches) | ARG[S] (int) | QUEUE[128] (u32)
 // REC is an array of per-sample RECORDS (field f of sample s at REC[s * NREC + f]), not one array per quantity: a
 // lane addresses its sample once and reaches every field, and the fields of its neighbours s +- 1, through the
 // immediate offset of the ds instruction.  (One array per quantity needs one base address per array; with 22 of
 // them the scalar registers ran out and the compiler parked them in VGPR lanes, ~450 v_readlane per candidate.)
 // NREC is odd, so that the 64 lanes of a ds_read_b64 / ds_read_b32 of one field fall into distinct banks.
-//   fields of every launch:   P0 P1 P2 CC SS YW D D1x D1y D1z                       (10, NREC = 11)
-//   gradient launches add:    A1x A1y A1z A2x A2y A2z SEGW                          (17, NREC = 17)
-// d cost / d d_k of the gradient launches (GD) lives in the MINKEY array, which is dead once the clearances have been
-// read out of it; the clearance-chain gradient is formed inside the gather loop (no arrays of its own).
+//   fields of every launch:   P0 P1 P2 YW D1x D1y D1z                               ( 7, NREC =  7)
+//   gradient launches add:    A1x A1y A1z A2x A2y A2z SEGW GD                       (15, NREC = 15)
+// Fields with disjoint lifetimes share a slot:
+//   D1* (first derivative) is dead once the curvature pass has run; the clearance phase then keeps CC, SS (cos / sin of
+//       the collision sample's yaw) and D (its clearance) there; D in turn is dead after the clearance terms, and the
+//       gather writes the yaw gradient GW into its slot;
+//   A1* holds the adjoint of d1, then (in place) T1 = A1 + G^T A2; A2* is dead after that and takes the gather's GX GY GZ;
+//   GD (d cost / d d_k) of an fp64 gradient launch is also where the sample's ordered clearance key lives during the
+//       clearance phase (same 8 bytes, same owner lane), so those launches have no MINKEY array.
+// The clearance-chain gradient is formed inside the gather loop (no arrays of its own).
 // W holds 4 * max(C, Cy) elements, rounded up to 16 (EvalArgs::w_elems).
-// S = 64, fp64: 10.1 KB per wave with gradient (16 waves per CU fit the 160 KB), 6.7 KB without.
-enum RecField : int { kP0 = 0, kP1, kP2, kCC, kSS, kYW, kD, kD1x, kD1y, kD1z,
-                      kA1x, kA1y, kA1z, kA2x, kA2y, kA2z, kSEGW };
-__host__ __device__ constexpr int rec_fields(bool grad) { return grad ? 17 : 11; }
+// fp64: S = 64 8.4 KB per wave with gradient, 4.9 KB without; S = 101 12.9 KB (12 waves per CU; 17 fields + MINKEY: 10).
+enum RecField : int { kP0 = 0, kP1, kP2, kYW, kD1x, kD1y, kD1z,
+                      kA1x, kA1y, kA1z, kA2x, kA2y, kA2z, kSEGW, kGD,
+                      kCC = kD1x, kSS = kD1y, kD = kD1z, kGX = kA2x, kGY = kA2y, kGZ = kA2z, kGW = kD1z };
+__host__ __device__ constexpr int rec_fields(bool grad) { return grad ? 15 : 7; }
+// the ordered clearance keys live inside the records (field kGD) instead of an array of their own
+__host__ __device__ constexpr bool key_in_record(bool grad, int e) { return grad && e == 8; }
 __host__ __device__ inline int w_elems_for(int C, int Cy) { return ((4 * (C > Cy ? C : Cy)) + 15) & ~15; }
 __host__ __device__ inline int lds_bytes_per_wave(int S, int e, bool grad, int w_elems)
 {
     int b = (w_elems + rec_fields(grad) * S) * e;
     b = (b + 7) & ~7;
-    b += 8 * S + 4 * S + 4 * 128;
+    if (!key_in_record(grad, e)) b += 8 * S;
+    b += 4 * S + 4 * 128;
     return (b + 15) & ~15;
 }
-constexpr int kChunkRec = 7;   // record of clearance_kernel: P0 P1 P2 CC SS YW + 1 (odd)
+constexpr int kChunkRec = 7;   // record of clearance_kernel: P0 P1 P2 YW CC SS + 1 (odd)
 
 // ---- culled clearance of one chunk of <= 64 collision samples (one per lane) against a task's boxes ----
 // REC: the per-sample records (fields kP0 kP1 kP2 kYW read at the sample, kCC kSS written at the collision
 // sample's own record; LOCAL: record = the lane's slot 0..63); MINKEY/ARG point at the chunk's first slot.  SEED: start from an upper bound taken from one representative box per group (used by the split
 // kernel, which serves every scene large enough to have groups).  On return MINKEY[slot] holds the ordered key of the scene value, ARG[slot] the deciding box
-// (-1: none) and the records' kCC/kSS the (cos, sin) of the sample's yaw.
-template <typename T, int ROT, bool LOCAL, bool SEED, int NREC, typename AT>
+// (-1: none) and the records' kCC/kSS the (cos, sin) of the sample's yaw.  KS: distance, in keys, between the keys of
+// consecutive slots (1: an array; NREC: the keys are a field of the fp64 records).
+template <typename T, int ROT, bool LOCAL, bool SEED, int NREC, int KS = 1, typename AT>
 __device__ __forceinline__ void clearance_chunk(const AT &a, const BoxRec<T> *boxes, const BoxRec32 *boxes32, const BoxPair32 *pairs,
                                                 const BoxRec32 *groups, int ngroups, int n_wide, int lane, int k0, int Sp, T *REC,
                                                 unsigned long long *MINKEY, int *ARG, unsigned int *QUEUE)
@@ -181,7 +192,7 @@ __device__ __forceinline__ void clearance_chunk(const AT &a, const BoxRec<T> *bo
         T c, sn;
         yaw_rot(rs[kYW], a.trig, c, sn);
         rk[kCC] = c; rk[kSS] = sn;
-        MINKEY[lane] = key_init<T>();
+        MINKEY[lane * KS] = key_init<T>();
         ARG[lane] = -1;
         px32 = (float)rs[kP0]; py32 = (float)rs[kP1]; pz32 = (float)rs[kP2];
         const float c32 = __builtin_fabsf((float)c), s32 = __builtin_fabsf((float)sn);
@@ -250,21 +261,21 @@ __device__ __forceinline__ void clearance_chunk(const AT &a, const BoxRec<T> *bo
                 if (!(po.gsat > T(0)) && !(po.gz > T(0))) atomicAdd(&g_stats[6], 1ull);
             }
 #endif
-            oldk = MINKEY[kk];
+            oldk = MINKEY[kk * KS];
         }
         wave_lds_sync();
-        if (act) atomicMin(&MINKEY[kk], key);
+        if (act) atomicMin(&MINKEY[kk * KS], key);
         wave_lds_sync();
         bool win = false;
         if (act) {
-            const unsigned long long newk = MINKEY[kk];
+            const unsigned long long newk = MINKEY[kk * KS];
             win = key == newk;
             if (win && newk < oldk) ARG[kk] = 0x7fffffff;  // strictly better: restart the argmin
         }
         wave_lds_sync();
         if (win) atomicMin(&ARG[kk], bb);  // ties: lowest box index, like a first-minimum scan
         wave_lds_sync();
-        if (valid) U32 = __builtin_fminf(U32, (float)key_to_sep2<T>(MINKEY[lane]) * (1.0f + 4e-6f));   // never above the seed
+        if (valid) U32 = __builtin_fminf(U32, (float)key_to_sep2<T>(MINKEY[lane * KS]) * (1.0f + 4e-6f));   // never above the seed
     };
 
     // Wide box first (a table, a floor; chosen on the host, axis-aligned scenes only, record 0 of the table).  Where
@@ -282,9 +293,9 @@ __device__ __forceinline__ void clearance_chunk(const AT &a, const BoxRec<T> *bo
             const T *rw = REC + sw * NREC;
             const T gz = mp_abs(rw[kP2] - eb.cz) - (a.az + eb.hz);
             if (mp_abs(rw[kP0] - eb.cx) <= eb.hx && mp_abs(rw[kP1] - eb.cy) <= eb.hy && gz > T(0)) {
-                MINKEY[lane] = kSepBit | Key<T>::bits(mp_fma(gz, gz, T(0)));   // the slot is still at its initial value
+                MINKEY[lane * KS] = kSepBit | Key<T>::bits(mp_fma(gz, gz, T(0)));   // the slot is still at its initial value
                 ARG[lane] = bi;
-                U32 = __builtin_fminf(U32, (float)key_to_sep2<T>(MINKEY[lane]) * (1.0f + 4e-6f));
+                U32 = __builtin_fminf(U32, (float)key_to_sep2<T>(MINKEY[lane * KS]) * (1.0f + 4e-6f));
                 need = false;
             }
         }
@@ -392,11 +403,14 @@ __global__ void __launch_bounds__(256, (eval_min_waves<T, GRAD, ROT>())) eval_ke
     constexpr int NREC = rec_fields(GRAD);
     T *REC = W + a.w_elems;
 #define RF(s_, f_) REC[(s_) * NREC + (f_)]
-    unsigned long long *MINKEY = reinterpret_cast<unsigned long long *>(
-        smem_raw + (size_t)wib * a.lds_per_wave + (((a.w_elems + NREC * S_layout) * sizeof(T) + 7) & ~(size_t)7));
-    int *ARG = reinterpret_cast<int *>(MINKEY + S_layout);
+    // ordered clearance keys: field kGD of the records (fp64 gradient launches: stride NREC keys) or an array behind them
+    constexpr bool KEYREC = key_in_record(GRAD, (int)sizeof(T));
+    constexpr int KS = KEYREC ? NREC : 1;
+    unsigned char *behind = smem_raw + (size_t)wib * a.lds_per_wave + (((a.w_elems + NREC * S_layout) * sizeof(T) + 7) & ~(size_t)7);
+    unsigned long long *MINKEY = KEYREC ? reinterpret_cast<unsigned long long *>(REC + (GRAD ? (int)kGD : 0))
+                                        : reinterpret_cast<unsigned long long *>(behind);
+    int *ARG = reinterpret_cast<int *>(behind + (KEYREC ? 0 : 8 * (size_t)S_layout));
     unsigned int *QUEUE = reinterpret_cast<unsigned int *>(ARG + S_layout);
-    T *GDa = reinterpret_cast<T *>(MINKEY);   // d cost / d d_k, written after the clearances have left MINKEY
     MP_PHASE_DECL;
     for (long long cand = (long long)blockIdx.x * wpb + wib; cand < a.n; cand += (long long)gridDim.x * wpb) {
         MP_ARGS_REFRESH();
@@ -535,12 +549,8 @@ __global__ void __launch_bounds__(256, (eval_min_waves<T, GRAD, ROT>())) eval_ke
                     RF(s, kA2x) = gcy * v1z - gcz * v1y; RF(s, kA2y) = gcz * v1x - gcx * v1z; RF(s, kA2z) = gcx * v1y - gcy * v1x;
                 }
             }
-        } else if (GRAD) {
-            for (int s = lane; s < S; s += 64) {
-                RF(s, kA1x) = T(0); RF(s, kA1y) = T(0); RF(s, kA1z) = T(0);
-                RF(s, kA2x) = T(0); RF(s, kA2y) = T(0); RF(s, kA2z) = T(0);
-            }
         }
+        wave_lds_sync();   // the clearance phase reuses the D1 fields (CC SS D)
 
         }
         MP_PHASE(2);  // curvature
@@ -568,11 +578,11 @@ __global__ void __launch_bounds__(256, (eval_min_waves<T, GRAD, ROT>())) eval_ke
             const int ngroups = __builtin_amdgcn_readfirstlane(tk.group_count);
             const int n_wide = __builtin_amdgcn_readfirstlane(tk.n_wide);
             for (int k0 = 0; k0 < Sp; k0 += 64) {
-                clearance_chunk<T, ROT, false, false, NREC>(a, boxes, boxes32, a.pairs + __builtin_amdgcn_readfirstlane(tk.spair_begin), groups,
-                                                            ngroups, n_wide, lane, k0, Sp, REC, MINKEY + k0, ARG + k0, QUEUE);
+                clearance_chunk<T, ROT, false, false, NREC, KS>(a, boxes, boxes32, a.pairs + __builtin_amdgcn_readfirstlane(tk.spair_begin), groups,
+                                                                ngroups, n_wide, lane, k0, Sp, REC, MINKEY + k0 * KS, ARG + k0, QUEUE);
                 const int k = k0 + lane;
                 if (k < Sp) {
-                    const T d = key_to_distance<T>(MINKEY[k]);
+                    const T d = key_to_distance<T>(MINKEY[k * KS]);
                     RF(k, kD) = d;
                     if (a.dist) a.dist[cand * a.Sp + k] = d;
                 }
@@ -652,7 +662,7 @@ __global__ void __launch_bounds__(256, (eval_min_waves<T, GRAD, ROT>())) eval_ke
                     gd -= w[9] * T(2) * e;
                 }
             }
-            if (GRAD) GDa[k] = gd;
+            if (GRAD) RF(k, kGD) = gd;
         }
 
         }
@@ -766,7 +776,7 @@ __global__ void __launch_bounds__(256, (eval_min_waves<T, GRAD, ROT>())) eval_ke
             MP_ARGS_REFRESH();
             {
             MP_LOCALS;
-            // (2) curvature: T1 = A1 + G^T A2 (kept in D1*).  (G^T v)[s] = cm v[s-1] + c0 v[s] + cp v[s+1]
+            // (2) curvature: T1 = A1 + G^T A2 (in place in A1*).  (G^T v)[s] = cm v[s-1] + c0 v[s] + cp v[s+1]
             // with the transposed np.gradient coefficients of row s (ends one-sided, inside central).
             const bool curv = (mask & 2u) && S >= 3;
             if (curv) {
@@ -775,9 +785,9 @@ __global__ void __launch_bounds__(256, (eval_min_waves<T, GRAD, ROT>())) eval_ke
                     const T cp = s == S - 2 ? -inv_du : ((s <= S - 3) ? -inv_h2 : T(0));
                     const T c0 = s == 0 ? -inv_du : (s == S - 1 ? inv_du : T(0));
                     const int lo = s == 0 ? 0 : s - 1, hi = s == S - 1 ? s : s + 1;
-                    RF(s, kD1x) = RF(s, kA1x) + (cm * RF(lo, kA2x) + c0 * RF(s, kA2x) + cp * RF(hi, kA2x));
-                    RF(s, kD1y) = RF(s, kA1y) + (cm * RF(lo, kA2y) + c0 * RF(s, kA2y) + cp * RF(hi, kA2y));
-                    RF(s, kD1z) = RF(s, kA1z) + (cm * RF(lo, kA2z) + c0 * RF(s, kA2z) + cp * RF(hi, kA2z));
+                    RF(s, kA1x) = RF(s, kA1x) + (cm * RF(lo, kA2x) + c0 * RF(s, kA2x) + cp * RF(hi, kA2x));
+                    RF(s, kA1y) = RF(s, kA1y) + (cm * RF(lo, kA2y) + c0 * RF(s, kA2y) + cp * RF(hi, kA2y));
+                    RF(s, kA1z) = RF(s, kA1z) + (cm * RF(lo, kA2z) + c0 * RF(s, kA2z) + cp * RF(hi, kA2z));
                 }
             }
             wave_lds_sync();
@@ -794,7 +804,7 @@ __global__ void __launch_bounds__(256, (eval_min_waves<T, GRAD, ROT>())) eval_ke
                 {   // clearance chain: d cost/d d_k * d d_k/d(P, yaw) of the collision sample taken at this spline sample
                     const int k = a.idx_identity ? s : a.inv_idx[s];
                     if (k >= 0 && k < Sp) {
-                        const T gd = GDa[k];
+                        const T gd = RF(k, kGD);
                         const int arg = ARG[k];
                         if (gd != T(0) && arg >= 0) {
                             const BoxRec<T> bx = boxes[arg];
@@ -830,9 +840,9 @@ __global__ void __launch_bounds__(256, (eval_min_waves<T, GRAD, ROT>())) eval_ke
                     const T cp = s == S - 2 ? -inv_du : ((s <= S - 3) ? -inv_h2 : T(0));
                     const T c0 = s == 0 ? -inv_du : (s == S - 1 ? inv_du : T(0));
                     const int lo = s == 0 ? 0 : s - 1, hi = s == S - 1 ? s : s + 1;
-                    gx += cm * RF(lo, kD1x) + c0 * RF(s, kD1x) + cp * RF(hi, kD1x);
-                    gy += cm * RF(lo, kD1y) + c0 * RF(s, kD1y) + cp * RF(hi, kD1y);
-                    gz += cm * RF(lo, kD1z) + c0 * RF(s, kD1z) + cp * RF(hi, kD1z);
+                    gx += cm * RF(lo, kA1x) + c0 * RF(s, kA1x) + cp * RF(hi, kA1x);
+                    gy += cm * RF(lo, kA1y) + c0 * RF(s, kA1y) + cp * RF(hi, kA1y);
+                    gz += cm * RF(lo, kA1z) + c0 * RF(s, kA1z) + cp * RF(hi, kA1z);
                 }
                 if (s == S - 1) { gx += gnx; gy += gny; gz += gnz; }
                 if (s == gn_first) { gx -= gnx; gy -= gny; gz -= gnz; }
@@ -857,7 +867,7 @@ __global__ void __launch_bounds__(256, (eval_min_waves<T, GRAD, ROT>())) eval_ke
                     T target = y0 + (y1 - y0) * tsched[s];
                     gw += w[13] * T(2) * (yw - target);
                 }
-                RF(s, kA1x) = gx; RF(s, kA1y) = gy; RF(s, kA1z) = gz; RF(s, kA2x) = gw;
+                RF(s, kGX) = gx; RF(s, kGY) = gy; RF(s, kGZ) = gz; RF(s, kGW) = gw;   // slots dead by now (see RecField)
             }
             wave_lds_sync();
             }
@@ -877,7 +887,7 @@ __global__ void __launch_bounds__(256, (eval_min_waves<T, GRAD, ROT>())) eval_ke
                     const bool is_pos = o < 3 * nf;
                     const int jj = is_pos ? o / 3 : o - 3 * nf;
                     const int comp = is_pos ? o - 3 * jj : 0;
-                    const T *V = REC + (is_pos ? (int)kA1x + comp : (int)kA2x);
+                    const T *V = REC + (is_pos ? (int)kGX + comp : (int)kGW);
                     const T *Mc = is_pos ? M + ff + jj : My + 1 + jj;
                     const int ld = is_pos ? C : Cy;
                     // eight (M, g) pairs fetched per trip, then the same in-order fma chain (a one-at-a-time loop

@@ -124,8 +124,8 @@ def test_maximum_sizes(S, oracle_lib):
         try:
             ctx = native.Context(0)
             ctx.set_problem(prob)
-            # a gradient launch keeps 17 fields per sample and wave in LDS: MP_MAX_SAMPLES = 1024 fp64 samples are a 153 KB
-            # slice, one wave per CU (round 1: 22 arrays, gradient launches beyond ~860 samples were refused)
+            # a gradient launch keeps 15 fields + 4 bytes per sample and wave in LDS: MP_MAX_SAMPLES = 1024 fp64 samples are a
+            # 125 KB slice, one wave per CU (round 1: 22 arrays, gradient launches beyond ~860 samples were refused)
             out = ctx.eval(X, want_grad=True, want_dist=True)
             _compare(out, ref, np.float64)
             out = ctx.eval(X, want_grad=False, want_terms=True, want_dist=True)
