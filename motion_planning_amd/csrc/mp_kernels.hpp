@@ -202,8 +202,15 @@ __device__ __forceinline__ void clearance_chunk(const AT &a, const BoxRec<T> *bo
         eys = __builtin_fmaf(c32, ay32, s32 * ax32) + slack;
         ezs = az32 + slack;
     }
-    // the mover's inflated world AABB (the rounding of these six operations is far inside the slack)
-    const float mlox = px32 - exs, mloy = py32 - eys, mloz = pz32 - ezs, mhix = px32 + exs, mhiy = py32 + eys, mhiz = pz32 + ezs;
+    // the mover's inflated world AABB (the rounding of these six operations is far inside the slack).  Once the lane's
+    // sample is known to penetrate some box by `depth`, the AABB is SHRUNK by a little less than that depth: the
+    // penetration value of a pair is minus the smallest projection overlap over all directions, so it cannot exceed
+    // the overlap of the two world AABBs along x, y or z; against the shrunk AABB a box whose overlap along some axis
+    // is below the current depth shows a positive gap (lb2 > 0 = U32) and is culled by the very same test, while a
+    // box that could be as deep or deeper still gives lb2 = 0.  Group AABBs contain their boxes, so the group test
+    // inherits the bound.  (In a cluttered scene a penetrating sample overlaps the AABBs of ~20 boxes; one or two of
+    // them can be the deepest.)
+    float mlox = px32 - exs, mloy = py32 - eys, mloz = pz32 - ezs, mhix = px32 + exs, mhiy = py32 + eys, mhiz = pz32 + ezs;
     // running upper bound of the lane's squared clearance; -1 on lanes without a sample, so that `lb2 <= U32`
     // alone (one v_cmp, whose result is the ballot) says whether the lane needs a pair
     float U32 = valid ? __builtin_huge_valf() : -1.0f;
@@ -275,7 +282,16 @@ __device__ __forceinline__ void clearance_chunk(const AT &a, const BoxRec<T> *bo
         wave_lds_sync();
         if (win) atomicMin(&ARG[kk], bb);  // ties: lowest box index, like a first-minimum scan
         wave_lds_sync();
-        if (valid) U32 = __builtin_fminf(U32, (float)key_to_sep2<T>(MINKEY[lane * KS]) * (1.0f + 4e-6f));   // never above the seed
+        if (valid) {
+            const unsigned long long kcur = MINKEY[lane * KS];
+            U32 = __builtin_fminf(U32, (float)key_to_sep2<T>(kcur) * (1.0f + 4e-6f));   // never above the seed
+            if (!(kcur & kSepBit)) {
+                // penetrating: shrink by the depth, rounded down (4e-6 relative covers the conversion to fp32)
+                const float dsh = (float)Key<T>::from_bits(Key<T>::kInfBits - kcur) * (1.0f - 4e-6f);
+                mlox = (px32 - exs) + dsh; mloy = (py32 - eys) + dsh; mloz = (pz32 - ezs) + dsh;
+                mhix = (px32 + exs) - dsh; mhiy = (py32 + eys) - dsh; mhiz = (pz32 + ezs) - dsh;
+            }
+        }
     };
 
     // Wide box first (a table, a floor; chosen on the host, axis-aligned scenes only, record 0 of the table).  Where

@@ -135,3 +135,53 @@ def test_maximum_sizes(S, oracle_lib):
             ctx.close()
         finally:
             os.environ.pop("MP_SPLIT_CLEARANCE", None)
+
+
+@pytest.mark.parametrize("variant", ["axis_aligned", "rotated", "tilted", "many_groups"])
+def test_deep_and_tied_penetrations_match_oracle(variant, oracle_lib):
+    """The culling bound of a penetrating sample (clearance_chunk: the mover's AABB shrunk by the depth found so far)
+    must keep every box that can be as deep or deeper: nested boxes around the path (each deeper than the one before),
+    exact duplicates (equal depths: the lowest index decides the argmin, hence the gradient) and boxes that only graze
+    the mover.  Clearance profile and deciding-box gradient against the brute-force oracle."""
+    from motion_planning_amd import _native as native
+    from motion_planning_amd.blocks import Block
+    from motion_planning_amd.synthetic import BoxList
+
+    rng = np.random.default_rng({"axis_aligned": 1, "rotated": 2, "tilted": 3, "many_groups": 4}[variant])
+    start, goal = np.array([-1.5, -1.5, 1.2]), np.array([1.5, 1.5, 0.8])
+    blocks = [Block(size=(4.0, 4.0, 0.1), position=(0.0, 0.0, 0.05), object_id="table")]
+    mid = 0.5 * (start + goal)
+    for k in range(6):            # nested around the middle of the path, outermost first
+        sz = 2.4 - 0.35 * k
+        blocks.append(Block(size=(sz, sz, sz * 0.8), position=tuple(mid + 0.02 * k), object_id=f"nest_{k}"))
+    for k in range(4):            # exact duplicates
+        blocks.append(Block(size=(0.8, 0.7, 0.9), position=(-0.6, -0.7, 1.0), object_id=f"dup_{k}"))
+    n_more = 300 if variant == "many_groups" else 20
+    for k in range(n_more):       # clutter that overlaps the path corridor
+        t = rng.random()
+        c = start + t * (goal - start) + rng.normal(size=3) * 0.35
+        blocks.append(Block(size=tuple(rng.uniform(0.1, 0.9, 3)), position=tuple(c), object_id=f"c_{k}"))
+    prob = build_path_problem(BoxList(blocks), start, goal, native.build_basis, n_vias=2, n_samples_curve=101,
+                              moving_block_size=(0.9, 0.6, 0.6), start_yaw_deg=0.0, goal_yaw_deg=90.0, combined_4d=True,
+                              n_yaw_vias=2, safety_margin=0.02, preferred_safety_margin=0.08, w_safe=80.0,
+                              w_safe_preferred=5.0, w_approach_collision=50.0, w_approach_clearance=5.0,
+                              approach_only_clearance=0.05)
+    if variant == "rotated":
+        prob = H.with_rotated_statics(prob, seed=5)
+    elif variant == "tilted":
+        prob = H.with_tilted_statics(prob, seed=6, fraction=0.5)
+    X = prob.x0 + 0.4 * prob.sigma0 * rng.normal(size=(96, prob.dim))
+    ref = oracle_lib.evaluate(prob, X)
+    assert (ref["dist"] < -0.2).mean() > 0.2, "the scene is meant to produce deep penetrations"
+    for force in ("0", "1"):
+        import os
+
+        os.environ["MP_SPLIT_CLEARANCE"] = force
+        try:
+            ctx = native.Context(0)
+            ctx.set_problem(prob)
+            out = ctx.eval(X, want_grad=True, want_dist=True)
+            _compare(out, ref, np.float64)
+            ctx.close()
+        finally:
+            os.environ.pop("MP_SPLIT_CLEARANCE", None)
