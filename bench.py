@@ -172,6 +172,10 @@ def main():
                     help="only the W + K launches of the headline kernel (what tools/pmc_passes.sh and the rocprofv3 --stats run "
                          "profile): no side metrics, no CPU baseline")
     ap.add_argument("--sustained-s", type=float, default=1.0, help="length of the sustained leg after the headline (N = 1)")
+    ap.add_argument("--settle-s", type=float, default=0.5,
+                    help="seconds of back-to-back launches of the same step on every rank BEFORE the W warm-up steps, so that the "
+                         "timed K steps run at settled clocks whatever W and K are (the first ~10 ms after an idle phase run ~7 %% "
+                         "slower); not part of the timed region, reported as extras.settle_launches")
     ap.add_argument("--dtype", default="f64", choices=["f64", "f32"])
     args = ap.parse_args()
 
@@ -238,6 +242,15 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    # clock settling (see --settle-s): plain launches of the step's kernel, no collectives
+    settle_launches = 0
+    if args.settle_s > 0 and not args.profile_mode:
+        t_end = time.perf_counter() + args.settle_s
+        while time.perf_counter() < t_end:
+            for _ in range(64):
+                db.evaluate(X)
+            torch.cuda.synchronize()
+            settle_launches += 64
     pend = []
     for i in range(args.warmup):
         step(i, pend)
@@ -300,7 +313,7 @@ def main():
         except Exception:
             traffic, executed, achieved, frac = None, None, None, None
 
-    extras = {}
+    extras = {"settle_launches": settle_launches, "settle_note": "untimed launches of the same step before the warm-up steps (clock settling, --settle-s)"}
     if args.profile_mode:
         if rank == 0:
             print(json.dumps({"profile_mode": True, "kernel_ms": kern_ms, "ms_per_step": elapsed / args.steps * 1e3, "steps": args.steps}))
