@@ -172,6 +172,9 @@ def main():
                     help="only the W + K launches of the headline kernel (what tools/pmc_passes.sh and the rocprofv3 --stats run "
                          "profile): no side metrics, no CPU baseline")
     ap.add_argument("--sustained-s", type=float, default=1.0, help="length of the sustained leg after the headline (N = 1)")
+    ap.add_argument("--gather-every", type=int, default=8,
+                    help="N > 1: the (cost, min clearance, flags) of this many consecutive steps go into ONE all-gather (a ring of "
+                         "result buffers per rank; fewer, larger collectives: a gather per 0.4 ms step costs ~8 %% of the step)")
     ap.add_argument("--settle-s", type=float, default=0.5,
                     help="seconds of back-to-back launches of the same step on every rank BEFORE the W warm-up steps, so that the "
                          "timed K steps run at settled clocks whatever W and K are (the first ~10 ms after an idle phase run ~7 %% "
@@ -214,27 +217,51 @@ def main():
     problem = synthetic_problem(_native.build_basis, N_BOXES, N_SAMPLES, seed=0)
     Xh = synthetic_candidates(problem, N_CAND, seed=100 + rank, dtype=np_dtype)   # this rank's index shard
     X = torch.from_numpy(Xh).cuda()
-    # two output slots: the collectives of step i read slot i % 2 while step i + 1 computes into the other one
-    dbs = [DeviceBatch(problem, N_CAND, device=local_rank, dtype=np_dtype, want_grad=True) for _ in range(2 if distributed else 1)]
+    # two rings of G result buffers: the collective of one group of G steps reads ring g % 2 while the next G steps compute
+    # into the other one
+    G = max(1, args.gather_every) if distributed else 1
+    dbs = [DeviceBatch(problem, N_CAND, device=local_rank, dtype=np_dtype, want_grad=True, result_slots=G)
+           for _ in range(2 if distributed else 1)]
     db = dbs[0]
     # collectives run on device tensors over RCCL; the gloo rehearsal (one-GPU box) stages them through the host
     coll_dev = "cuda" if backend == "nccl" else "cpu"
     if distributed:
-        gather_buf = [torch.empty(world * db.results_bytes.numel(), dtype=torch.uint8, device=coll_dev) for _ in range(2)]
+        gather_buf = [torch.empty(world * G * db.slot_bytes, dtype=torch.uint8, device=coll_dev) for _ in range(2)]
 
-    def step(i, pending):
-        cur = dbs[i % len(dbs)]
-        if distributed and len(pending) >= 2:
-            for w in pending.pop(0):   # the collective that read this slot two steps ago: long finished as a rule, and
-                if not w.is_completed():   # then the compute stream needs no wait packet in front of the next launch
-                    w.wait()
-        out = cur.evaluate(X)
-        if distributed:
-            # the kernel's own output buffer goes into the collective (cost, min clearance and flags share one allocation):
-            # no packing kernel, one gather per step on RCCL's stream while the next step computes into the other slot
-            res = cur.results_bytes if coll_dev == "cuda" else cur.results_bytes.cpu()
-            pending.append((dist.all_gather_into_tensor(gather_buf[i % 2], res, async_op=True),))
+    sent = [0, 0]   # per ring: first entry of the current group not yet handed to a collective
+
+    def step(i, pending, n_steps):
+        """Step i of a run of n_steps.  Collectives: one per group of G steps, except that the run's last group is cut
+        after its second-to-last step, so that only ONE step's results (1.1 MB per rank) are still to be exchanged when
+        the last kernel ends and the bulk of the last group travels under that kernel."""
+        grp, slot = (i // G) % len(dbs), i % G
+        cur = dbs[grp]
+        if distributed and slot == 0:
+            sent[grp] = 0
+            if len(pending) >= 2:
+                for w in pending.pop(0)[1]:   # the collectives that read this ring two groups ago: long finished as a rule,
+                    if not w.is_completed():   # and then the compute stream needs no wait packet in front of the next launch
+                        w.wait()
+        out = cur.evaluate(X, slot=slot)
+        if distributed and (slot == G - 1 or i >= n_steps - 2):
+            # the kernels' own output buffers go into the collective (cost, min clearance and flags of a step share one
+            # allocation, the steps of a group are consecutive in it): no packing kernel, the gather runs on RCCL's stream
+            # while the next steps compute
+            f, k = sent[grp], slot + 1
+            res = cur.results_ring[f:k].reshape(-1)
+            if coll_dev != "cuda":
+                res = res.cpu()
+            dst = gather_buf[grp][world * f * db.slot_bytes: world * k * db.slot_bytes]
+            w = dist.all_gather_into_tensor(dst, res, async_op=True)
+            if pending and pending[-1][0] == (i // G):
+                pending[-1][1].append(w)
+            else:
+                pending.append(((i // G), [w]))
+            sent[grp] = k
+            last_gather.update(grp=grp, first=f, end=k)
         return out
+
+    last_gather = {}
 
     def sync():
         torch.cuda.synchronize()
@@ -242,19 +269,27 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    # first use of every collective of the job (communicator set-up, first barrier: tens of ms on RCCL) happens here, not
+    # between the warm-up and the timed steps, where the idle GPU would drop its clocks
+    if distributed:
+        dist.barrier()
+        dist.all_gather_into_tensor(gather_buf[0], dbs[0].results_ring.reshape(-1) if coll_dev == "cuda" else dbs[0].results_ring.reshape(-1).cpu())
+        t_warm = torch.zeros(1, dtype=torch.float64, device=coll_dev)
+        dist.all_reduce(t_warm, op=dist.ReduceOp.MAX)
+        dist.barrier()
     # clock settling (see --settle-s): plain launches of the step's kernel, no collectives
     settle_launches = 0
     if args.settle_s > 0 and not args.profile_mode:
         t_end = time.perf_counter() + args.settle_s
         while time.perf_counter() < t_end:
-            for _ in range(64):
-                db.evaluate(X)
+            for j in range(64):   # every context and every ring entry is touched here, not first inside the timed region
+                dbs[(j // G) % len(dbs)].evaluate(X, slot=j % G)
             torch.cuda.synchronize()
             settle_launches += 64
     pend = []
     for i in range(args.warmup):
-        step(i, pend)
-    for ws in pend:
+        step(i, pend, args.warmup)
+    for _, ws in pend:
         for w in ws:
             w.wait()
     sync()
@@ -265,13 +300,24 @@ def main():
     t0 = time.perf_counter()
     db.ctx.timer_start()
     for i in range(args.steps):
-        step(i, pend)
+        step(i, pend, args.steps)
     kern_ms = db.ctx.timer_stop() / max(args.steps, 1)   # waits for the last launch
-    for ws in pend:
+    t_k = time.perf_counter()
+    for _, ws in pend:
         for w in ws:
             w.wait()
+    torch.cuda.synchronize()
+    t_g = time.perf_counter()
     sync()
     elapsed = time.perf_counter() - t0
+    tail_ms = {"last_launch_done": (t_k - t0) * 1e3, "gathers_done": (t_g - t0) * 1e3, "barrier_done": elapsed * 1e3}
+    gather_ok = None
+    if distributed:
+        # this rank's own rows of the last collective are the bytes its kernels wrote
+        grp, f, k = last_gather["grp"], last_gather["first"], last_gather["end"]
+        region = gather_buf[grp][world * f * db.slot_bytes: world * k * db.slot_bytes]
+        mine = region[rank * (k - f) * db.slot_bytes: (rank + 1) * (k - f) * db.slot_bytes]
+        gather_ok = bool(torch.equal(mine.cpu(), dbs[grp].results_ring[f:k].reshape(-1).cpu()))
     if distributed:
         t = torch.tensor([elapsed], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -313,7 +359,7 @@ def main():
         except Exception:
             traffic, executed, achieved, frac = None, None, None, None
 
-    extras = {"settle_launches": settle_launches, "settle_note": "untimed launches of the same step before the warm-up steps (clock settling, --settle-s)"}
+    extras = {"timed_region_ms": tail_ms, "gather_own_rows_match": gather_ok, "settle_launches": settle_launches, "settle_note": "untimed launches of the same step before the warm-up steps (clock settling, --settle-s)"}
     if args.profile_mode:
         if rank == 0:
             print(json.dumps({"profile_mode": True, "kernel_ms": kern_ms, "ms_per_step": elapsed / args.steps * 1e3, "steps": args.steps}))
@@ -422,7 +468,8 @@ def main():
             "config": {"workload": "BASELINE config 3: 65,536 multi-start spline candidates x 64 samples x 50 axis-aligned "
                                    "boxes per GPU, 15-term box-model cost + gradient + min clearance + flags",
                        "candidates_per_gpu": N_CAND, "n_samples": N_SAMPLES, "n_boxes": N_BOXES, "dim": problem.dim,
-                       "parallelism": f"index-sharded x{world}, async all-gather of (cost,min_clear,flags)"},
+                       "parallelism": f"index-sharded x{world}, async all-gather of (cost,min_clear,flags)"
+                                      + (f", one collective per {G} steps" if distributed else "")},
             "roofline": {"bound": "fp64_valu" if args.dtype == "f64" else "fp32_valu", "achieved": achieved, "peak": peak,
                          "unit": "TFLOP/s", "frac": frac, "traffic": traffic,
                          "kernel_ms": kern_ms, "executed": executed,

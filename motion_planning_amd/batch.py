@@ -35,7 +35,8 @@ class DeviceBatch:
     output tensors; nothing is copied to the host."""
 
     def __init__(self, problems: Sequence[PathProblem] | PathProblem, capacity: int, device: Optional[int] = None,
-                 dtype=np.float64, want_grad: bool = True, want_terms: bool = False, cands_per_task: int = 0):
+                 dtype=np.float64, want_grad: bool = True, want_terms: bool = False, cands_per_task: int = 0,
+                 result_slots: int = 1):
         from . import _native
 
         if not torch.cuda.is_available():
@@ -57,16 +58,25 @@ class DeviceBatch:
         # ... and the flags follow in the same allocation: `results_bytes` (cost | min clearance | flags as raw bytes) is
         # what a job hands to ONE all-gather per step
         es = self.np_dtype.itemsize
-        self.results_bytes = torch.empty((2 * es + 1) * capacity, dtype=torch.uint8, device=dev)
-        self.cost_minc = self.results_bytes[:2 * es * capacity].view(self.tdtype).view(2, capacity)
-        self.cost = self.cost_minc[0]
-        self.min_clear = self.cost_minc[1]
-        self.flags = self.results_bytes[2 * es * capacity:]
+        # `result_slots` > 1: a ring of result buffers in ONE allocation (evaluate(..., slot=k) writes ring entry k), so that
+        # a job can hand the results of several consecutive batches to one collective (`results_ring[:k]`)
+        self.result_slots = max(1, int(result_slots))
+        self.slot_bytes = (2 * es + 1) * capacity
+        self.results_ring = torch.empty(self.result_slots, self.slot_bytes, dtype=torch.uint8, device=dev)
+        self._slot_views = []
+        for k in range(self.result_slots):
+            rb = self.results_ring[k]
+            cm = rb[:2 * es * capacity].view(self.tdtype).view(2, capacity)
+            self._slot_views.append((rb, cm, cm[0], cm[1], rb[2 * es * capacity:]))
+        self.results_bytes, self.cost_minc, self.cost, self.min_clear, self.flags = self._slot_views[0]
         self.grad = torch.empty(capacity, D, dtype=self.tdtype, device=dev) if want_grad else None
         self.terms = torch.empty(capacity, abi.MP_NTERMS, dtype=self.tdtype, device=dev) if want_terms else None
 
-    def evaluate(self, X: torch.Tensor, task_of: Optional[torch.Tensor] = None) -> Dict[str, torch.Tensor]:
+    def evaluate(self, X: torch.Tensor, task_of: Optional[torch.Tensor] = None, slot: int = 0) -> Dict[str, torch.Tensor]:
         n = X.shape[0]
+        if not 0 <= slot < self.result_slots:
+            raise ValueError(f"result slot {slot} outside the ring of {self.result_slots}")
+        _, _, cost, min_clear, flags = self._slot_views[slot]
         if n > self.capacity:
             raise ValueError("batch larger than the preallocated capacity")
         if X.dtype != self.tdtype or not X.is_cuda or not X.is_contiguous() or X.ndim != 2 or X.shape[1] != self.problem.dim:
@@ -84,11 +94,11 @@ class DeviceBatch:
             self.ctx.set_stream(stream)
             self._stream = stream
         self.ctx.eval_device(
-            n, X.data_ptr(), self.cost.data_ptr(), self.terms.data_ptr() if self.terms is not None else 0,
-            self.grad.data_ptr() if self.grad is not None else 0, self.min_clear.data_ptr(), self.flags.data_ptr(), 0,
+            n, X.data_ptr(), cost.data_ptr(), self.terms.data_ptr() if self.terms is not None else 0,
+            self.grad.data_ptr() if self.grad is not None else 0, min_clear.data_ptr(), flags.data_ptr(), 0,
             task_of.data_ptr() if task_of is not None else 0,
         )
-        out = {"cost": self.cost[:n], "min_clear": self.min_clear[:n], "flags": self.flags[:n]}
+        out = {"cost": cost[:n], "min_clear": min_clear[:n], "flags": flags[:n]}
         if self.grad is not None:
             out["grad"] = self.grad[:n]
         if self.terms is not None:
