@@ -225,6 +225,38 @@ def test_device_pointer_call_can_be_captured_into_a_graph(native):
     db.close()
 
 
+def test_result_ring_entries_are_independent(native):
+    """DeviceBatch(result_slots=G): evaluate(..., slot=k) writes ring entry k only; the ring is one allocation whose first
+    k entries are what a job hands to one collective (bench.py, one all-gather per G steps)."""
+    import torch
+
+    from motion_planning_amd.batch import DeviceBatch
+    from motion_planning_amd.synthetic import synthetic_candidates, synthetic_problem
+
+    prob = synthetic_problem(native.build_basis, 50, 64, seed=0)
+    n, G = 1000, 3
+    Xs = [torch.from_numpy(synthetic_candidates(prob, n, seed=20 + k)).cuda() for k in range(G)]
+    one = DeviceBatch(prob, n, want_grad=True)
+    refs = [{k: v.clone() for k, v in one.evaluate(X).items()} for X in Xs]
+    ring = DeviceBatch(prob, n, want_grad=True, result_slots=G)
+    ring.results_ring.fill_(0xAB)
+    for k in (2, 0, 1):
+        out = ring.evaluate(Xs[k], slot=k)
+        assert torch.equal(out["grad"], refs[k]["grad"])
+    torch.cuda.synchronize()
+    assert ring.results_ring.shape == (G, 17 * n) and ring.results_ring.is_contiguous()
+    for k in range(G):
+        raw = ring.results_ring[k]
+        assert torch.equal(raw[: 8 * n].view(torch.float64), refs[k]["cost"])
+        assert torch.equal(raw[8 * n: 16 * n].view(torch.float64), refs[k]["min_clear"])
+        assert torch.equal(raw[16 * n:], refs[k]["flags"])
+    assert torch.equal(ring.results_bytes, ring.results_ring[0])      # the single-slot names are ring entry 0
+    with pytest.raises(ValueError, match="result slot"):
+        ring.evaluate(Xs[0], slot=G)
+    one.close()
+    ring.close()
+
+
 def test_error_paths(native):
     ctx = native.Context(0)
     prob = H.problem_for_case(CASES[0])
