@@ -27,6 +27,8 @@ def main():
     ap.add_argument("--max-iter", type=int, default=90)
     ap.add_argument("--seed", type=int, default=2)
     ap.add_argument("--dtype", default="f64", choices=["f64", "f32"])
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"])
+    ap.add_argument("--one-device", action="store_true", help="every rank uses cuda:0 (rehearsal on a one-GPU box)")
     args = ap.parse_args()
     import torch
     import torch.distributed as dist
@@ -37,10 +39,15 @@ def main():
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
+    local = 0 if args.one_device else int(os.environ.get("LOCAL_RANK", "0"))
     if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group("gloo")
+        dist.barrier()      # RCCL's first collective takes tens of ms: not inside the timed solve
     t_build = time.perf_counter()
     probs = wall_scenario_problems(_native.build_basis, args.scenarios, seed=args.seed)
     mine = probs[rank::world]
@@ -51,16 +58,26 @@ def main():
     t0 = time.perf_counter()
     res = solve_scenarios_cem(mine, restarts=args.restarts, device=local if world > 1 else 0, dtype=dt,
                               population_size=args.population, max_iter=args.max_iter, seed=args.seed + 1000 * rank)
-    solved_local = torch.tensor([float(res["solved"].sum()), float(len(mine)), float(res["nit"].sum()) * args.population],
-                                dtype=torch.float64, device="cuda")
+    # the path's only exchange: ONE all-gather of per-scenario (best cost, solved flag, generations), shards padded to equal length
+    width = (args.scenarios + world - 1) // world
+    rows = torch.zeros(width, 3, dtype=torch.float64, device="cuda")
+    rows[:, 1] = -1.0                                   # padding rows: no scenario
+    k = len(mine)
+    rows[:k, 0] = torch.as_tensor(np.asarray(res["fun"], dtype=np.float64)).cuda()
+    rows[:k, 1] = torch.as_tensor(np.asarray(res["solved"], dtype=np.float64)).cuda()
+    rows[:k, 2] = torch.as_tensor(np.asarray(res["nit"], dtype=np.float64).sum(axis=1)).cuda()
     if world > 1:
-        gathered = [torch.empty_like(solved_local) for _ in range(world)]
-        dist.all_gather(gathered, solved_local)
-        tot = torch.stack(gathered).sum(dim=0)
+        src = rows if args.backend == "nccl" else rows.cpu()     # gloo moves host memory
+        gathered = torch.empty(world * width, 3, dtype=torch.float64, device=src.device)
+        dist.all_gather_into_tensor(gathered, src)
         torch.cuda.synchronize()
         dist.barrier()
+        # scenario j lives in row (j // world) of rank (j % world)
+        full = gathered.view(world, width, 3).permute(1, 0, 2).reshape(world * width, 3)[: args.scenarios].cpu()
     else:
-        tot = solved_local
+        full = rows[: args.scenarios].cpu()
+    assert bool((full[:, 1] >= 0).all()), "a scenario is missing from the gathered table"
+    tot = torch.tensor([float(full[:, 1].sum()), float(full.shape[0]), float(full[:, 2].sum()) * args.population])
     elapsed = time.perf_counter() - t0
     if rank == 0:
         n_solved, n_all, evals = (float(v) for v in tot.cpu())
@@ -68,7 +85,7 @@ def main():
             "metric": "scenarios solved/sec", "value": n_solved / elapsed, "unit": "scenarios/s", "n_gpus": world,
             "scenarios": int(n_all), "restarts": args.restarts, "solved": int(n_solved), "solved_fraction": n_solved / n_all,
             "wall_s": elapsed, "objective_evals": evals, "evals_per_s": evals / elapsed, "dtype": args.dtype,
-            "scenario_build_s": t_build,
+            "scenario_build_s": t_build, "best_cost_sum_of_solved": float(full[full[:, 1] > 0, 0].sum()),
             "config": {"workload": "BASELINE config 5: generated wall-building scenarios x restarts, CEM to the reference "
                                    "stopping rule, S=101, BASE_CONFIG", "population": args.population, "max_iter": args.max_iter},
         }))
