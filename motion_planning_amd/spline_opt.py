@@ -296,7 +296,8 @@ def _cem_optimize_multi(objective, x0, sigma0, seeds, population_size: int = 48,
 
 
 def _refine_with_gradient(value_and_grad: Callable, x: np.ndarray, sigma0: np.ndarray, iters: int = 40, copies: int = 2,
-                          jitter: float = 0.05, step0: float = 0.05, seed: Optional[int] = None, **_ignored) -> Dict:
+                          jitter: float = 0.05, step0: float = 0.05, seed: Optional[int] = None, ftol: float = 1e-10,
+                          patience: int = 3, **_ignored) -> Dict:
     """Batched local refinement with the analytic (sub)gradient — the stand-in for the reference's derivative-free Powell
     stage (ref :338-359) that a batched evaluator makes cheap.  ``x``: one start (D,) or several (R, D); every start is
     refined ``copies`` times (the first copy exact, the others jittered by ``jitter * sigma0``), all of them together, ONE
@@ -308,7 +309,8 @@ def _refine_with_gradient(value_and_grad: Callable, x: np.ndarray, sigma0: np.nd
     that defeat the plain gradient); +-sigma0_j * level probes along every coordinate at six scales (the batched
     counterpart of the bracketing line searches Powell runs along each direction: robust at the kinks of the
     sub-gradient); and repeats of the last accepted move.  Monotone: a copy never gets worse.
-    ``value_and_grad(X) -> (cost (n,), grad (n, D))``."""
+    Stops before ``iters`` once the best cost has not improved by more than ``ftol`` (relative) for ``patience``
+    consecutive iterations.  ``value_and_grad(X) -> (cost (n,), grad (n, D))``."""
     rng = np.random.default_rng(seed)
     scale = np.asarray(sigma0, dtype=float)
     starts = np.atleast_2d(np.asarray(x, dtype=float))
@@ -333,7 +335,9 @@ def _refine_with_gradient(value_and_grad: Callable, x: np.ndarray, sigma0: np.nd
     last = np.zeros((R, D))
     Hinv = np.zeros((R, D, D))          # inverse Hessian estimate in scaled coordinates z = x / sigma0; zero until the first update
     rows = np.arange(R)
+    nit, stalled, best_so_far = 0, 0, float(np.min(cost))
     for _ in range(int(iters)):
+        nit += 1
         gz = grad * scale[None, :]
         unit = gz / np.maximum(np.linalg.norm(gz, axis=1, keepdims=True), 1e-30)
         dz = -np.einsum("rij,rj->ri", Hinv, gz)
@@ -369,8 +373,13 @@ def _refine_with_gradient(value_and_grad: Callable, x: np.ndarray, sigma0: np.nd
         on_line = better & (j < A)
         grow = on_line & (al[np.minimum(j, A - 1)] >= 2.0)
         step = np.maximum(np.where(grow, step * 2.0, np.where(on_line, step, step * 0.5)), 1e-5)
+        now = float(np.min(cost))
+        stalled = stalled + 1 if best_so_far - now <= ftol * abs(now) else 0
+        best_so_far = min(best_so_far, now)
+        if stalled >= int(patience):
+            break
     i = int(np.argmin(cost))
-    return {"x": X[i].copy(), "fun": float(cost[i]), "nit": int(iters), "n_eval": int(n_eval), "all_fun": cost.copy()}
+    return {"x": X[i].copy(), "fun": float(cost[i]), "nit": int(nit), "n_eval": int(n_eval), "all_fun": cost.copy()}
 
 
 def _solve_optimizer(objective_single, x0, sigma0, method: str, options: Optional[Dict] = None,

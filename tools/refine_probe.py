@@ -37,4 +37,5 @@ for name, raw in scen.items():
         rows.append(rec)
         print(f"{name:30s} seed {seed:2d}: CEM-POWELL {rec['CEM-POWELL']['fun']:12.4f} ({rec['CEM-POWELL']['calls']:4d} calls, {rec['CEM-POWELL']['wall_ms']:6.1f} ms)  "
               f"CEM-GRAD {rec['CEM-GRAD']['fun']:12.4f} ({rec['CEM-GRAD']['calls']:4d} calls, {rec['CEM-GRAD']['wall_ms']:6.1f} ms)  {rec['ratio'] - 1:+.2%}", flush=True)
-(ROOT / "profiles" / "r02_cem_grad_vs_powell.json").write_text(json.dumps(rows, indent=1))
+out = ROOT / "gpurun_out" if (ROOT / "gpurun_out").is_dir() else ROOT / "profiles"   # on the GPU box only gpurun_out/ travels back
+(out / "r02_cem_grad_vs_powell.json").write_text(json.dumps(rows, indent=1))
