@@ -168,6 +168,7 @@ __host__ __device__ inline int lds_bytes_per_wave(int S, int e, bool grad, int w
     b += 4 * S + 4 * 128;
     return (b + 15) & ~15;
 }
+constexpr int kSeedStride = 8;   // the bound of a grouped scene is seeded from the representative of every 8th group
 constexpr int kChunkRec = 7;   // record of clearance_kernel: P0 P1 P2 YW CC SS + 1 (odd)
 
 // ---- culled clearance of one chunk of <= 64 collision samples (one per lane) against a task's boxes ----
@@ -220,9 +221,11 @@ __device__ __forceinline__ void clearance_chunk(const AT &a, const BoxRec<T> *bo
         // Seed of the upper bound: the mover's centre lies in the mover and a box's centre in the box, so the scene
         // value is at most the distance from this sample to the centre of any box.  One representative box per
         // group (record 2g+1), coordinates inflated by the slack, keeps the first groups of the sweep from
-        // being evaluated against an infinite bound.
+        // being evaluated against an infinite bound.  Every kSeedStride-th group is enough: the groups are visited
+        // nearest to the nominal path first and the bound tightens within the first exact passes (measured on the
+        // config-4 shape: every group 1.013 ms, every 2nd 0.960, 4th 0.941, 8th 0.932, 16th .. none 0.940).
         float ub = __builtin_huge_valf();
-        for (int g = 0; g < ngroups; ++g) {
+        for (int g = 0; g < ngroups; g += kSeedStride) {
             const BoxRec32 rep = load_box32_uniform(groups, 2 * g + 1);
             const float dx = __builtin_fabsf(px32 - rep.lox) + slack, dy = __builtin_fabsf(py32 - rep.loy) + slack,
                         dz = __builtin_fabsf(pz32 - rep.loz) + slack;
