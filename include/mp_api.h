@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define MP_API_VERSION 1
+#define MP_API_VERSION 2
 
 /* ---- limits ------------------------------------------------------------------ */
 #define MP_MAX_CTRL 16    /* waypoints per spline (start + vias + goal)            */
@@ -272,6 +272,9 @@ typedef struct mp_cem_options {
     double alpha;            /* 0.7 */
     double min_sigma;        /* 1e-3 */
     uint64_t seed;           /* device Philox stream (ignored when `noise` is given) */
+    uint64_t instance_base;  /* instance i of this call draws from stream instance_base + i: a job that shards a
+                                list of instances over ranks passes the index of its first one, and the draws
+                                (hence the results) do not depend on the partition; 0 for a single call   */
 } mp_cem_options;
 
 /*   task_of_inst [n_inst] or NULL  task of each instance (NULL: instance i -> task i / insts_per_task,

@@ -7,7 +7,7 @@ from __future__ import annotations
 
 import ctypes as C
 
-MP_API_VERSION = 1
+MP_API_VERSION = 2
 MP_MAX_CTRL = 16
 MP_MAX_SAMPLES = 1024
 MP_NTERMS = 15
@@ -109,4 +109,5 @@ class MpCemOptions(C.Structure):
         ("alpha", C.c_double),
         ("min_sigma", C.c_double),
         ("seed", C.c_uint64),
+        ("instance_base", C.c_uint64),
     ]

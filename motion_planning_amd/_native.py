@@ -247,8 +247,9 @@ class Context:
     # -- device-resident CEM over many instances --
     def cem_solve(self, x0: np.ndarray, sigma0: np.ndarray, task_of: Optional[np.ndarray] = None, population_size: int = 64,
                   elite_frac: float = 0.2, max_iter: int = 90, tol: float = 1e-3, alpha: float = 0.7, min_sigma: float = 1e-3,
-                  seed: Optional[int] = None, noise: Optional[np.ndarray] = None):
-        """Batched _cem_optimize (geom/spline_opt.py:222-277): one instance per row of x0."""
+                  seed: Optional[int] = None, noise: Optional[np.ndarray] = None, instance_base: int = 0):
+        """Batched _cem_optimize (geom/spline_opt.py:222-277): one instance per row of x0.  ``instance_base``: global index of
+        row 0 when the rows are one rank's share of a longer list (the device noise streams are keyed by global index)."""
         p = self.problem
         if p is None:
             raise RuntimeError("set_problem first")
@@ -257,7 +258,8 @@ class Context:
         n = x0.shape[0]
         sigma0 = np.ascontiguousarray(np.broadcast_to(np.asarray(sigma0, dtype=dt), x0.shape))
         opt = abi.MpCemOptions(int(population_size), int(max_iter), float(elite_frac), float(tol), float(alpha),
-                               float(min_sigma), int(seed if seed is not None else np.random.SeedSequence().entropy & (2**63 - 1)))
+                               float(min_sigma), int(seed if seed is not None else np.random.SeedSequence().entropy & (2**63 - 1)),
+                               int(instance_base))
         if noise is not None:
             noise = np.ascontiguousarray(noise, dtype=dt)
             if noise.shape != (max_iter, n, population_size, p.dim):

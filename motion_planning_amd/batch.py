@@ -161,21 +161,23 @@ def best_feasible(cost: torch.Tensor, flags: torch.Tensor) -> Tuple[int, float, 
 
 
 def solve_scenarios_cem(problems: Sequence[PathProblem], restarts: int = 32, device: int = 0, dtype=np.float64,
-                        restart_seed: int = 0, **cem_options) -> Dict[str, np.ndarray]:
+                        restart_seed: int = 0, scenario_base: int = 0, **cem_options) -> Dict[str, np.ndarray]:
     """Scenario-parallel planning (BASELINE config 5): every scenario gets ``restarts`` independent CEM
     solves started from x0 + sigma0 * eps (restart 0 from x0 itself), all instances advance in lock-step
     on the GPU, and the best restart of each scenario is returned.
 
-    "solved" follows SURVEY.md §8d: the best candidate is feasible (min clearance >= required)."""
+    "solved" follows SURVEY.md §8d: the best candidate is feasible (min clearance >= required).
+    ``scenario_base``: global index of ``problems[0]`` when the list is one rank's contiguous share of a longer one.  The
+    restart offsets and the device noise streams are keyed by GLOBAL scenario / instance index, so a scenario's result
+    does not depend on how the list is partitioned over ranks (tests/test_gpu_evidence.py)."""
     from . import _native
 
     p0 = problems[0]
     n_s, D = len(problems), p0.dim
-    rng = np.random.default_rng(restart_seed)
     x0 = np.empty((n_s, restarts, D))
     s0 = np.empty((n_s, restarts, D))
     for i, p in enumerate(problems):
-        eps = rng.normal(size=(restarts, D))
+        eps = np.random.default_rng([int(restart_seed), int(scenario_base) + i]).normal(size=(restarts, D))
         eps[0] = 0.0
         x0[i] = p.x0[None, :] + eps * p.sigma0[None, :]
         s0[i] = p.sigma0[None, :]
@@ -183,7 +185,8 @@ def solve_scenarios_cem(problems: Sequence[PathProblem], restarts: int = 32, dev
     try:
         ctx.set_problem(list(problems))
         task_of = np.repeat(np.arange(n_s, dtype=np.int32), restarts)
-        res = ctx.cem_solve(x0.reshape(-1, D), s0.reshape(-1, D), task_of=task_of, **cem_options)
+        res = ctx.cem_solve(x0.reshape(-1, D), s0.reshape(-1, D), task_of=task_of,
+                            instance_base=int(scenario_base) * int(restarts), **cem_options)
     finally:
         ctx.close()
     fun = res["fun"].astype(float).reshape(n_s, restarts)

@@ -630,7 +630,7 @@ int cem_solve(mp_ctx *ctx, long long n_inst, const int32_t *d_task, const T *d_x
     // one generation: sample, evaluate, tick (generation counter + running count), update — all on the stream
     auto generation = [&](const T *noise_g) -> int {
         hipLaunchKernelGGL(mp::cem_sample_kernel<T>, dim3(sb), dim3(256), 0, ctx->stream, n_inst, pop, D, st, noise_g,
-                           (unsigned long long)o.seed, (T *)ctx->c_X.p);
+                           (unsigned long long)o.seed, (unsigned long long)o.instance_base, (T *)ctx->c_X.p);
         if (hipGetLastError() != hipSuccess) return MP_E_HIP;
         int r = launch_eval<T>(ctx, (long long)np_, ctx->c_X.p, nullptr, ctx->c_vals.p, nullptr, nullptr, ctx->c_minc.p,
                                (uint8_t *)ctx->c_flags.p, nullptr, pop, d_task, (const uint8_t *)ctx->c_done.p);

@@ -1100,7 +1100,7 @@ template <typename T> struct CemState {
 template <typename T>
 __global__ void __launch_bounds__(256) cem_sample_kernel(long long n_inst, int pop, int D, CemState<T> st,
                                                           const T *__restrict__ noise, unsigned long long seed,
-                                                          T *__restrict__ X)
+                                                          unsigned long long inst_base, T *__restrict__ X)
 {
     const long long total = n_inst * pop * D;
     const int gen = *st.gen;
@@ -1113,7 +1113,8 @@ __global__ void __launch_bounds__(256) cem_sample_kernel(long long n_inst, int p
             eps = noise[e];
         } else {
             unsigned int r[4];
-            Philox::generate(seed, (unsigned long long)e, (unsigned long long)gen, r);
+            // the counter is the element's index in the GLOBAL list of instances (inst_base = this call's first one)
+            Philox::generate(seed, inst_base * (unsigned long long)pop * D + (unsigned long long)e, (unsigned long long)gen, r);
             const double u1 = ((double)r[0] * 4294967296.0 + (double)r[1] + 1.0) * (1.0 / 18446744073709551616.0);  // (0,1]
             const double u2 = ((double)r[2] * 4294967296.0 + (double)r[3]) * (1.0 / 18446744073709551616.0);        // [0,1)
             eps = (T)(::sqrt(-2.0 * ::log(u1)) * ::cospi(2.0 * u2));

@@ -39,15 +39,17 @@ def test_struct_layout_matches_the_header(tmp_path):
     src = tmp_path / "sz.c"
     src.write_text(
         '#include <stdio.h>\n#include <stddef.h>\n#include "mp_api.h"\n'
-        'int main(void){printf("%zu %zu %zu %zu %zu %zu %zu\\n", sizeof(mp_config), sizeof(mp_task),'
+        'int main(void){printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu\\n", sizeof(mp_config), sizeof(mp_task),'
         ' offsetof(mp_config, weights), offsetof(mp_config, idx_safe), offsetof(mp_config, t_sched),'
-        ' offsetof(mp_task, goal_normal), offsetof(mp_task, box_count));return 0;}\n'
+        ' offsetof(mp_task, goal_normal), offsetof(mp_task, box_count), sizeof(mp_cem_options),'
+        ' offsetof(mp_cem_options, instance_base));return 0;}\n'
     )
     exe = tmp_path / "sz"
     subprocess.run(["gcc", "-I", str(ROOT / "include"), str(src), "-o", str(exe)], check=True)
     got = [int(v) for v in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split()]
     want = [C.sizeof(abi.MpConfig), C.sizeof(abi.MpTask), abi.MpConfig.weights.offset, abi.MpConfig.idx_safe.offset,
-            abi.MpConfig.t_sched.offset, abi.MpTask.goal_normal.offset, abi.MpTask.box_count.offset]
+            abi.MpConfig.t_sched.offset, abi.MpTask.goal_normal.offset, abi.MpTask.box_count.offset,
+            C.sizeof(abi.MpCemOptions), abi.MpCemOptions.instance_base.offset]
     assert got == want
 
 

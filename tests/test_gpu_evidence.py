@@ -241,3 +241,33 @@ def test_config4_job_gathers_what_one_gpu_computes(mode, tmp_path, native, oracl
     np.testing.assert_array_equal(ref["min_clear"], rows[idx, 1])
     np.testing.assert_array_equal(ref["flags"], rows[idx, 2].astype(np.uint8))
     assert H.rel_err(rows[idx, 0], ref["cost"]).max() < 1e-9
+
+
+def test_config5_job_does_not_depend_on_the_partition(tmp_path, native):
+    """tools/run_config5.py (config 5 at reduced size: 97 scenarios x 8 restarts, an odd count so the shards are ragged) in
+    this process's partition-free form (solve_scenarios_cem over all scenarios) and as a torchrun child with two ranks over
+    gloo sharing the GPU: restart offsets and the device Philox streams are keyed by the GLOBAL scenario / instance index
+    (mp_cem_options.instance_base), so the gathered per-scenario (best cost, solved, generations) rows are the same
+    bytes whatever the number of ranks."""
+    from motion_planning_amd.batch import solve_scenarios_cem
+    from motion_planning_amd.synthetic import wall_scenario_problems
+
+    n_sc, restarts = 97, 8
+    dump = tmp_path / "c5.npy"
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), str(ROOT / "tools" / "run_config5.py"), "--scenarios", str(n_sc), "--restarts",
+           str(restarts), "--population", "48", "--max-iter", "40", "--seed", "5", "--backend", "gloo", "--one-device",
+           "--dump", str(dump)]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=170, env=env, cwd=str(ROOT))
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    rows = np.load(dump)
+    assert rows.shape == (n_sc, 3) and line["n_gpus"] == 2 and line["scenarios"] == n_sc
+    probs = wall_scenario_problems(native.build_basis, n_sc, seed=5)
+    one = solve_scenarios_cem(probs, restarts=restarts, population_size=48, max_iter=40, seed=5, restart_seed=5)
+    assert np.asarray(one["fun"], dtype=np.float64).tobytes() == rows[:, 0].tobytes()
+    np.testing.assert_array_equal(np.asarray(one["solved"], dtype=np.float64), rows[:, 1])
+    np.testing.assert_array_equal(np.asarray(one["nit"], dtype=np.float64).sum(axis=1), rows[:, 2])
+    assert line["solved"] == int(one["solved"].sum())

@@ -4,8 +4,9 @@ CEM solve to the reference's stopping rule, all instances in lock-step on the GP
 
   python tools/run_config5.py --scenarios 10000 --restarts 32
   python -m torch.distributed.run --nproc-per-node G --master-addr 127.0.0.1 tools/run_config5.py ...
-Scenarios are sharded by index (k mod G); the only exchange is one all-gather of per-scenario
-(best cost, solved flag)."""
+Scenarios are sharded by index in contiguous blocks (batch.shard_bounds); the only exchange is one all-gather of
+per-scenario (best cost, solved flag, generations).  Restart offsets and device noise streams are keyed by the GLOBAL
+scenario index, so the gathered table does not depend on the number of ranks (`--dump` writes it for a checker)."""
 import argparse
 import json
 import os
@@ -29,12 +30,13 @@ def main():
     ap.add_argument("--dtype", default="f64", choices=["f64", "f32"])
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"])
     ap.add_argument("--one-device", action="store_true", help="every rank uses cuda:0 (rehearsal on a one-GPU box)")
+    ap.add_argument("--dump", default=None, help="rank 0 writes the gathered per-scenario table to this .npy")
     args = ap.parse_args()
     import torch
     import torch.distributed as dist
 
     from motion_planning_amd import _native
-    from motion_planning_amd.batch import solve_scenarios_cem
+    from motion_planning_amd.batch import shard_bounds, solve_scenarios_cem
     from motion_planning_amd.synthetic import wall_scenario_problems
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -50,16 +52,18 @@ def main():
         dist.barrier()      # RCCL's first collective takes tens of ms: not inside the timed solve
     t_build = time.perf_counter()
     probs = wall_scenario_problems(_native.build_basis, args.scenarios, seed=args.seed)
-    mine = probs[rank::world]
+    lo, hi = shard_bounds(args.scenarios, rank, world)
+    mine = probs[lo:hi]
     t_build = time.perf_counter() - t_build
     dt = np.float64 if args.dtype == "f64" else np.float32
     if world > 1:
         dist.barrier()
     t0 = time.perf_counter()
     res = solve_scenarios_cem(mine, restarts=args.restarts, device=local if world > 1 else 0, dtype=dt,
-                              population_size=args.population, max_iter=args.max_iter, seed=args.seed + 1000 * rank)
+                              population_size=args.population, max_iter=args.max_iter, seed=args.seed, restart_seed=args.seed,
+                              scenario_base=lo)
     # the path's only exchange: ONE all-gather of per-scenario (best cost, solved flag, generations), shards padded to equal length
-    width = (args.scenarios + world - 1) // world
+    width = max(b - a for a, b in (shard_bounds(args.scenarios, r, world) for r in range(world)))
     rows = torch.zeros(width, 3, dtype=torch.float64, device="cuda")
     rows[:, 1] = -1.0                                   # padding rows: no scenario
     k = len(mine)
@@ -72,13 +76,18 @@ def main():
         dist.all_gather_into_tensor(gathered, src)
         torch.cuda.synchronize()
         dist.barrier()
-        # scenario j lives in row (j // world) of rank (j % world)
-        full = gathered.view(world, width, 3).permute(1, 0, 2).reshape(world * width, 3)[: args.scenarios].cpu()
+        parts = []
+        for r in range(world):
+            a, b = shard_bounds(args.scenarios, r, world)
+            parts.append(gathered[r * width: r * width + (b - a)])
+        full = torch.cat(parts, dim=0).cpu()
     else:
         full = rows[: args.scenarios].cpu()
     assert bool((full[:, 1] >= 0).all()), "a scenario is missing from the gathered table"
     tot = torch.tensor([float(full[:, 1].sum()), float(full.shape[0]), float(full[:, 2].sum()) * args.population])
     elapsed = time.perf_counter() - t0
+    if rank == 0 and args.dump:
+        np.save(args.dump, full.numpy())
     if rank == 0:
         n_solved, n_all, evals = (float(v) for v in tot.cpu())
         print(json.dumps({
