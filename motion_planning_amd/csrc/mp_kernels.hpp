@@ -13,6 +13,9 @@ namespace mp {
 #ifndef MP_MIN_WAVES
 #define MP_MIN_WAVES 3
 #endif
+#ifndef MP_COST64_WAVES
+#define MP_COST64_WAVES 5   // waves per SIMD the fp64 cost-only kernels are register-budgeted for (<= 96 VGPRs)
+#endif
 #ifndef MP_GRAD64_WAVES
 #define MP_GRAD64_WAVES 4   // waves per SIMD the fp64 gradient kernels are register-budgeted for
 #endif
@@ -369,12 +372,13 @@ __device__ __forceinline__ void clearance_chunk(const AT &a, const BoxRec<T> *bo
 // ROT: 0 axis-aligned scene; 1 the scene holds yaw-rotated static boxes; 2 it also holds tilted ones (separate
 // instantiations keep the axis-aligned code as it was)
 // PRE: split mode, the clearance profile comes from clearance_kernel (box model only)
-// Waves per SIMD the register budget is sized for: fp64 kernels 4 (gradient 123 VGPRs, cost only 110; round 1 needed 168
-// for the gradient kernels: 3 waves), fp32 kernels 5 (<= 96 VGPRs).  None of the instances uses scratch memory.
+// Waves per SIMD the register budget is sized for: fp64 gradient kernels 4 (122 VGPRs), fp64 cost-only kernels 5 (95; round 1 needed 168
+// for the gradient kernels: 3 waves), fp32 kernels 5 (<= 96 VGPRs).  No scratch memory except one 8-byte accumulator per
+// lane in the fused fp64 cost-only box instances (profiles/r02_kernel_resources.txt).
 template <typename T, bool GRAD, int ROT = 0> constexpr int eval_min_waves()
 {
     return ROT == 2 ? 2   // the tilt routine is a real call: its registers count too
-                    : (sizeof(T) == 4 ? MP_MIN_WAVES + 2 : (GRAD ? MP_GRAD64_WAVES : MP_MIN_WAVES + 1));
+                    : (sizeof(T) == 4 ? MP_MIN_WAVES + 2 : (GRAD ? MP_GRAD64_WAVES : MP_COST64_WAVES));
 }
 
 template <typename T, int MODEL, bool GRAD, int ROT, bool PRE>
