@@ -13,6 +13,9 @@ namespace mp {
 #ifndef MP_MIN_WAVES
 #define MP_MIN_WAVES 3
 #endif
+#ifndef MP_CLR_WAVES
+#define MP_CLR_WAVES 6   // waves per SIMD clearance_kernel is register-budgeted for (measured: 4 0.934, 5 0.847, 6 0.792, 7 0.794, 8 0.815 ms)
+#endif
 #ifndef MP_COST64_WAVES
 #define MP_COST64_WAVES 5   // waves per SIMD the fp64 cost-only kernels are register-budgeted for (<= 96 VGPRs)
 #endif
@@ -965,7 +968,7 @@ __host__ __device__ inline int clearance_lds_bytes_per_wave(int e)
 }
 
 template <typename T, int ROT>
-__global__ void __launch_bounds__(256) clearance_kernel(const EvalArgs<T> a)
+__global__ void __launch_bounds__(256, (ROT == 2 ? 2 : MP_CLR_WAVES)) clearance_kernel(const EvalArgs<T> a)
 {
     extern __shared__ __align__(16) unsigned char smem_raw[];
     const int lane = threadIdx.x & 63;
