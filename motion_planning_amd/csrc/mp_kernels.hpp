@@ -10,8 +10,8 @@
 
 namespace mp {
 
-#ifndef MP_MIN_WAVES
-#define MP_MIN_WAVES 3
+#ifndef MP_F32_WAVES
+#define MP_F32_WAVES 7   // fp32 kernels: 72 VGPRs, no scratch (measured at config 3, cost + gradient: 5 waves 0.331 ms, 6 0.310, 7 0.303, 8 0.348)
 #endif
 #ifndef MP_CLR_WAVES
 #define MP_CLR_WAVES 6   // waves per SIMD clearance_kernel is register-budgeted for (measured: 4 0.934, 5 0.847, 6 0.792, 7 0.794, 8 0.815 ms)
@@ -376,12 +376,12 @@ __device__ __forceinline__ void clearance_chunk(const AT &a, const BoxRec<T> *bo
 // instantiations keep the axis-aligned code as it was)
 // PRE: split mode, the clearance profile comes from clearance_kernel (box model only)
 // Waves per SIMD the register budget is sized for: fp64 gradient kernels 4 (122 VGPRs), fp64 cost-only kernels 5 (95; round 1 needed 168
-// for the gradient kernels: 3 waves), fp32 kernels 5 (<= 96 VGPRs).  No scratch memory except one 8-byte accumulator per
+// for the gradient kernels: 3 waves), fp32 kernels 7 (72 VGPRs).  No scratch memory except one 8-byte accumulator per
 // lane in the fused fp64 cost-only box instances (profiles/r02_kernel_resources.txt).
 template <typename T, bool GRAD, int ROT = 0> constexpr int eval_min_waves()
 {
     return ROT == 2 ? 2   // the tilt routine is a real call: its registers count too
-                    : (sizeof(T) == 4 ? MP_MIN_WAVES + 2 : (GRAD ? MP_GRAD64_WAVES : MP_COST64_WAVES));
+                    : (sizeof(T) == 4 ? MP_F32_WAVES : (GRAD ? MP_GRAD64_WAVES : MP_COST64_WAVES));
 }
 
 template <typename T, int MODEL, bool GRAD, int ROT, bool PRE>
