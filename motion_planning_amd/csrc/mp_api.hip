@@ -22,6 +22,9 @@
 // address that hipGetSymbolAddress returned in mp_create (g_scratch_ptr); kernels get that pointer as an argument.
 static __device__ __align__(256) unsigned char scratch[MP_NOALLOC_SCRATCH_BYTES];
 
+#ifndef MP_WPB_PCT
+#define MP_WPB_PCT 75   // a smaller block must put a third more waves on the CU to be preferred (measured: 85, 75, 60)
+#endif
 namespace {
 
 void *g_scratch_ptr[64] = {nullptr};   // [device] address of that GPU's copy of `scratch` (each GPU has its own)
@@ -534,19 +537,22 @@ int launch_eval(mp_ctx *ctx, long long n, const void *X, const int32_t *task_of,
     if (per_wave > ctx->max_lds)
         return fail(ctx, MP_E_UNSUPPORTED, "n_samples_curve=%d needs %zu B of LDS per wave (limit %zu)", c.n_samples,
                     per_wave, ctx->max_lds);
-    // waves per block: whatever puts the most waves on a CU (blocks share its LDS), larger blocks on ties: a block's
-    // waves are spread over the CU's four SIMDs, several small blocks need not be (S=101 with gradient: 4 blocks of
-    // 2 waves 0.87 ms, 2 blocks of 4 waves 0.78 ms)
+    // waves per block: a block's waves are spread over the CU's four SIMDs, several small blocks need not be, so the
+    // largest block (up to four waves) wins unless a smaller one puts clearly more waves on the CU (blocks share its LDS).
+    // Measured: S=101 with gradient, 4 blocks of 2 waves 0.87 ms, 2 blocks of 4 waves 0.78 ms; point model S=121 cost only,
+    // 6 blocks of 3 waves (18 waves) 0.176 ms, 4 blocks of 4 (16 waves) 0.156 ms.
     int wpb = 1;
     {
-        size_t best = 0;
+        size_t waves_of[5] = {0, 0, 0, 0, 0}, best = 0;
+        // VGPR budget of the kernel variant (__launch_bounds__): waves per SIMD x 4 SIMDs per CU
+        const size_t vgpr_cap = (size_t)4 * (grad != nullptr ? mp::eval_min_waves<T, true>() : mp::eval_min_waves<T, false>());
         for (int w = 1; w <= 4; ++w) {
             if (per_wave * w > ctx->max_lds) break;
-            // VGPR budget of the kernel variant (__launch_bounds__): waves per SIMD x 4 SIMDs per CU
-            const size_t vgpr_cap = (size_t)4 * (grad != nullptr ? mp::eval_min_waves<T, true>() : mp::eval_min_waves<T, false>());
-            const size_t waves = std::min<size_t>(std::min<size_t>(ctx->max_lds / (per_wave * w), 16) * w, vgpr_cap);
-            if (waves >= best) { best = waves; wpb = w; }
+            waves_of[w] = std::min<size_t>(std::min<size_t>(ctx->max_lds / (per_wave * w), 16) * w, vgpr_cap);
+            best = std::max(best, waves_of[w]);
         }
+        for (int w = 1; w <= 4; ++w)
+            if (waves_of[w] > 0 && waves_of[w] * 100 >= best * MP_WPB_PCT) wpb = w;
     }
     const size_t lds_bytes = per_wave * wpb;
     long long need = (n + wpb - 1) / wpb;
