@@ -73,6 +73,7 @@ struct mp_ctx {
     int max_task_boxes = 0;
     int idx_identity = 0;         // idx_safe is 0, 1, 2, ...
     int split_mode = -1;          // -1 automatic, 0 never, 1 always (MP_SPLIT_CLEARANCE, tuning aid)
+    int five_wave_mode = -1;      // -1 automatic, 0 never (MP_FIVE_WAVES=0, tuning aid / A-B of the five-wave gradient instance)
     int cem_graph = 1;            // replay the CEM generations from a captured HIP graph (MP_CEM_GRAPH=0 turns it off)
 
     // device-resident CEM
@@ -471,7 +472,10 @@ template <typename T> int upload_problem(mp_ctx *ctx, const mp_task *tasks)
 template <typename T, int MODEL, bool GRAD, int ROT, bool PRE>
 int launch_eval_p(mp_ctx *ctx, const mp::EvalArgs<T> &args, int wpb, int blocks, size_t lds_bytes)
 {
-    auto kern = mp::eval_kernel<T, MODEL, GRAD, ROT, PRE>;
+    void (*kern)(const mp::EvalArgs<T>) = mp::eval_kernel<T, MODEL, GRAD, ROT, PRE>;
+    if constexpr (sizeof(T) == 8 && MODEL == 1 && GRAD && ROT == 0 && !PRE) {
+        if (args.five_waves) kern = mp::eval_kernel<T, MODEL, GRAD, ROT, PRE, 5>;
+    }
     if (lds_bytes > 65536) {
         // the opt-in for > 64 KB of dynamic LDS is per kernel variant and device: set once, raise when a larger slice comes
         static std::atomic<int> granted[64];
@@ -533,6 +537,19 @@ int launch_eval(mp_ctx *ctx, long long n, const void *X, const int32_t *task_of,
     a.cost = (T *)cost; a.terms = (T *)terms; a.grad = (T *)grad; a.minc = (T *)minc; a.dist = (T *)dist;
     a.flags = flags;
 
+    // Five-wave instance of the fp64 gradient kernel (mp_kernels.hpp, WV = 5): fused axis-aligned box scenes with one
+    // 64-sample chunk, < 1024 boxes per task and a waypoint table of <= 256 bytes, when five four-wave blocks of its compact
+    // slice fit the CU's LDS (handed out in granules of 1,280 bytes, 128 per CU)
+    {
+        const bool will_split = c.model == MP_MODEL_BOX &&
+                                (ext_scratch || ctx->split_mode == 1 ||
+                                 (ctx->split_mode < 0 && (ctx->max_task_boxes >= 128 || (c.n_safe > 64 && ctx->max_task_boxes >= 32))));
+        const size_t five_block = (size_t)4 * mp::lds_bytes_per_wave_five(c.n_samples);
+        a.five_waves = (sizeof(T) == 8 && grad != nullptr && c.model == MP_MODEL_BOX && !ctx->has_rot && !will_split &&
+                        c.n_samples <= 64 && ctx->max_task_boxes < 1024 && a.w_elems * (int)sizeof(T) <= 256 &&
+                        ((five_block + 1279) / 1280) * 5 <= ctx->max_lds / 1280 && ctx->five_wave_mode != 0) ? 1 : 0;
+        if (a.five_waves) a.lds_per_wave = mp::lds_bytes_per_wave_five(c.n_samples);
+    }
     const size_t per_wave = (size_t)a.lds_per_wave;
     if (per_wave > ctx->max_lds)
         return fail(ctx, MP_E_UNSUPPORTED, "n_samples_curve=%d needs %zu B of LDS per wave (limit %zu)", c.n_samples,
@@ -542,7 +559,8 @@ int launch_eval(mp_ctx *ctx, long long n, const void *X, const int32_t *task_of,
     // Measured: S=101 with gradient, 4 blocks of 2 waves 0.87 ms, 2 blocks of 4 waves 0.78 ms; point model S=121 cost only,
     // 6 blocks of 3 waves (18 waves) 0.176 ms, 4 blocks of 4 (16 waves) 0.156 ms.
     int wpb = 1;
-    {
+    if (a.five_waves) wpb = 4;
+    else {
         size_t waves_of[5] = {0, 0, 0, 0, 0}, best = 0;
         // VGPR budget of the kernel variant (__launch_bounds__): waves per SIMD x 4 SIMDs per CU
         const size_t vgpr_cap = (size_t)4 * (grad != nullptr ? mp::eval_min_waves<T, true>() : mp::eval_min_waves<T, false>());
@@ -755,6 +773,7 @@ int mp_create(int device_id, int dtype, mp_ctx **out)
     mp_ctx *ctx = new mp_ctx();
     ctx->device = device_id;
     if (const char *sm = std::getenv("MP_SPLIT_CLEARANCE")) ctx->split_mode = std::atoi(sm) != 0 ? 1 : 0;
+    if (const char *fw = std::getenv("MP_FIVE_WAVES")) ctx->five_wave_mode = std::atoi(fw) != 0 ? -1 : 0;
     if (const char *cg = std::getenv("MP_CEM_GRAPH")) ctx->cem_graph = std::atoi(cg) != 0 ? 1 : 0;
     ctx->dtype = dtype;
     auto bail = [&](const char *what, hipError_t err) {

@@ -64,6 +64,7 @@ template <typename T> struct EvalArgs {
     unsigned mask;
     int lds_per_wave;  // bytes
     int w_elems;       // elements of the waypoint table W in front of the records
+    int five_waves;    // 1: the launch uses the five-waves-per-SIMD instance and its compact LDS slice (see eval_kernel, WV)
     int n_tasks;
     T w[kNTerms];
     T req, pref, appr_tgt, goal_tgt, radius, ax, ay, az;
@@ -174,6 +175,8 @@ __host__ __device__ inline int lds_bytes_per_wave(int S, int e, bool grad, int w
     b += 4 * S + 4 * 128;
     return (b + 15) & ~15;
 }
+// slice of the five-wave instance (eval_kernel, WV = 5): records + 256 bytes (W / 16-bit queue / 16-bit deciding boxes)
+__host__ __device__ inline int lds_bytes_per_wave_five(int S) { return (15 * 8 * S + 256 + 15) & ~15; }
 constexpr int kSeedStride = 8;   // the bound of a grouped scene is seeded from the representative of every 8th group
 constexpr int kChunkRec = 7;   // record of clearance_kernel: P0 P1 P2 YW CC SS + 1 (odd)
 
@@ -183,7 +186,8 @@ constexpr int kChunkRec = 7;   // record of clearance_kernel: P0 P1 P2 YW CC SS 
 // kernel, which serves every scene large enough to have groups).  On return MINKEY[slot] holds the ordered key of the scene value, ARG[slot] the deciding box
 // (-1: none) and the records' kCC/kSS the (cos, sin) of the sample's yaw.  KS: distance, in keys, between the keys of
 // consecutive slots (1: an array; NREC: the keys are a field of the fp64 records).
-template <typename T, int ROT, bool LOCAL, bool SEED, int NREC, int KS = 1, typename AT>
+// AS: the same for the deciding-box words (in ints).  Q16: work-queue entries are 16 bits (lane << 10 | box; every task < 1024 boxes).
+template <typename T, int ROT, bool LOCAL, bool SEED, int NREC, int KS = 1, int AS = 1, bool Q16 = false, typename AT>
 __device__ __forceinline__ void clearance_chunk(const AT &a, const BoxRec<T> *boxes, const BoxRec32 *boxes32, const BoxPair32 *pairs,
                                                 const BoxRec32 *groups, int ngroups, int n_wide, int lane, int k0, int Sp, T *REC,
                                                 unsigned long long *MINKEY, int *ARG, unsigned int *QUEUE)
@@ -200,7 +204,7 @@ __device__ __forceinline__ void clearance_chunk(const AT &a, const BoxRec<T> *bo
         yaw_rot(rs[kYW], a.trig, c, sn);
         rk[kCC] = c; rk[kSS] = sn;
         MINKEY[lane * KS] = key_init<T>();
-        ARG[lane] = -1;
+        ARG[lane * AS] = -1;
         px32 = (float)rs[kP0]; py32 = (float)rs[kP1]; pz32 = (float)rs[kP2];
         const float c32 = __builtin_fabsf((float)c), s32 = __builtin_fabsf((float)sn);
         slack = 2e-6f * (__builtin_fabsf(px32) + __builtin_fabsf(py32) + __builtin_fabsf(pz32) +
@@ -248,9 +252,15 @@ __device__ __forceinline__ void clearance_chunk(const AT &a, const BoxRec<T> *bo
         unsigned long long key = ~0ull, oldk = 0ull;
         int kk = 0, bb = 0;
         if (act) {
-            const unsigned int e = QUEUE[(qhead + lane) & 127];
-            kk = (int)(e >> 24);
-            bb = (int)(e & 0xffffffu);
+            if (Q16) {
+                const unsigned int e = reinterpret_cast<const unsigned short *>(QUEUE)[(qhead + lane) & 127];
+                kk = (int)(e >> 10);
+                bb = (int)(e & 0x3ffu);
+            } else {
+                const unsigned int e = QUEUE[(qhead + lane) & 127];
+                kk = (int)(e >> 24);
+                bb = (int)(e & 0xffffffu);
+            }
             const int ss = LOCAL ? kk : sample_of(a, k0 + kk);
             const BoxRec<T> bx = boxes[bb];
             const T *rs = REC + ss * NREC, *rk = REC + (LOCAL ? kk : k0 + kk) * NREC;
@@ -286,10 +296,10 @@ __device__ __forceinline__ void clearance_chunk(const AT &a, const BoxRec<T> *bo
         if (act) {
             const unsigned long long newk = MINKEY[kk * KS];
             win = key == newk;
-            if (win && newk < oldk) ARG[kk] = 0x7fffffff;  // strictly better: restart the argmin
+            if (win && newk < oldk) ARG[kk * AS] = 0x7fffffff;  // strictly better: restart the argmin
         }
         wave_lds_sync();
-        if (win) atomicMin(&ARG[kk], bb);  // ties: lowest box index, like a first-minimum scan
+        if (win) atomicMin(&ARG[kk * AS], bb);  // ties: lowest box index, like a first-minimum scan
         wave_lds_sync();
         if (valid) {
             const unsigned long long kcur = MINKEY[lane * KS];
@@ -319,7 +329,7 @@ __device__ __forceinline__ void clearance_chunk(const AT &a, const BoxRec<T> *bo
             const T gz = mp_abs(rw[kP2] - eb.cz) - (a.az + eb.hz);
             if (mp_abs(rw[kP0] - eb.cx) <= eb.hx && mp_abs(rw[kP1] - eb.cy) <= eb.hy && gz > T(0)) {
                 MINKEY[lane * KS] = kSepBit | Key<T>::bits(mp_fma(gz, gz, T(0)));   // the slot is still at its initial value
-                ARG[lane] = bi;
+                ARG[lane * AS] = bi;
                 U32 = __builtin_fminf(U32, (float)key_to_sep2<T>(MINKEY[lane * KS]) * (1.0f + 4e-6f));
                 need = false;
             }
@@ -327,7 +337,8 @@ __device__ __forceinline__ void clearance_chunk(const AT &a, const BoxRec<T> *bo
         const unsigned long long m = __builtin_amdgcn_ballot_w64(need);
         if (need) {
             const int pos = __builtin_amdgcn_mbcnt_hi((unsigned int)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)m, 0u));
-            QUEUE[pos & 127] = ((unsigned int)lane << 24) | (unsigned int)bi;
+            if (Q16) reinterpret_cast<unsigned short *>(QUEUE)[pos & 127] = (unsigned short)(((unsigned int)lane << 10) | (unsigned int)bi);
+            else QUEUE[pos & 127] = ((unsigned int)lane << 24) | (unsigned int)bi;
         }
         qcount = __builtin_popcountll(m);
     }
@@ -349,7 +360,8 @@ __device__ __forceinline__ void clearance_chunk(const AT &a, const BoxRec<T> *bo
             if (m) {
                 if (need) {
                     const int pos = __builtin_amdgcn_mbcnt_hi((unsigned int)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)m, 0u));
-                    QUEUE[(qhead + qcount + pos) & 127] = ((unsigned int)lane << 24) | (unsigned int)idx;
+                    if (Q16) reinterpret_cast<unsigned short *>(QUEUE)[(qhead + qcount + pos) & 127] = (unsigned short)(((unsigned int)lane << 10) | (unsigned int)idx);
+                    else QUEUE[(qhead + qcount + pos) & 127] = ((unsigned int)lane << 24) | (unsigned int)idx;
                 }
                 qcount += __builtin_popcountll(m);
                 if (qcount >= 64) {
@@ -378,14 +390,22 @@ __device__ __forceinline__ void clearance_chunk(const AT &a, const BoxRec<T> *bo
 // Waves per SIMD the register budget is sized for: fp64 gradient kernels 4 (122 VGPRs), fp64 cost-only kernels 5 (95; round 1 needed 168
 // for the gradient kernels: 3 waves), fp32 kernels 7 (72 VGPRs).  No scratch memory except one 8-byte accumulator per
 // lane in the fused fp64 cost-only box instances (profiles/r02_kernel_resources.txt).
-template <typename T, bool GRAD, int ROT = 0> constexpr int eval_min_waves()
+template <typename T, bool GRAD, int ROT = 0, int WV = 0> constexpr int eval_min_waves()
 {
+    if (WV > 0) return WV;
     return ROT == 2 ? 2   // the tilt routine is a real call: its registers count too
                     : (sizeof(T) == 4 ? MP_F32_WAVES : (GRAD ? MP_GRAD64_WAVES : MP_COST64_WAVES));
 }
 
-template <typename T, int MODEL, bool GRAD, int ROT, bool PRE>
-__global__ void __launch_bounds__(256, (eval_min_waves<T, GRAD, ROT>())) eval_kernel(const EvalArgs<T> a_by_value)
+// WV = 5: the five-waves-per-SIMD instance of the fp64 gradient kernel (fused, axis-aligned box scenes, one 64-sample
+// chunk, < 1024 boxes per task, <= 8 waypoints): 96 VGPRs (~70 B of scratch per lane) and a slice of 15 * 8 * S + 256 bytes,
+// so that five four-wave blocks fit the CU's 128 LDS granules of 1,280 bytes at S = 64.  What it gives up to get there:
+//   * the waypoint table W shares its 256 bytes with the work queue (16-bit entries) and, after the clearance phase, with
+//     the deciding boxes as 16-bit values; the closed-form terms read the free waypoints from x itself;
+//   * during the exact passes the 32-bit deciding-box words (they need 32-bit LDS atomics) live in the low half of the
+//     records' kD slot, which is free until the clearance is written there at the end of the chunk.
+template <typename T, int MODEL, bool GRAD, int ROT, bool PRE, int WV = 0>
+__global__ void __launch_bounds__(256, (eval_min_waves<T, GRAD, ROT, WV>())) eval_kernel(const EvalArgs<T> a_by_value)
 {
     // The arguments are read through the kernel-argument segment pointer (the explicit arguments start at offset 0),
     // re-derived behind an opaque barrier at the start of every phase of the candidate loop (MP_ARGS_REFRESH).  Read as
@@ -424,19 +444,26 @@ __global__ void __launch_bounds__(256, (eval_min_waves<T, GRAD, ROT>())) eval_ke
     const int wib = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int wpb = (int)(blockDim.x >> 6);
     const int S_layout = a.S;   // inside the candidate loop every argument is re-read per phase (MP_LOCALS)
-    T *base = reinterpret_cast<T *>(smem_raw + (size_t)wib * a.lds_per_wave);
-    T *W = base;
+    constexpr bool FIVE = WV == 5;
+    static_assert(!FIVE || (sizeof(T) == 8 && GRAD && MODEL == 1 && !PRE), "the five-wave instance is the fused fp64 gradient kernel");
     constexpr int NREC = rec_fields(GRAD);
-    T *REC = W + a.w_elems;
+    T *base = reinterpret_cast<T *>(smem_raw + (size_t)wib * a.lds_per_wave);
+    T *REC = FIVE ? base : base + a.w_elems;
 #define RF(s_, f_) REC[(s_) * NREC + (f_)]
     // ordered clearance keys: field kGD of the records (fp64 gradient launches: stride NREC keys) or an array behind them
     constexpr bool KEYREC = key_in_record(GRAD, (int)sizeof(T));
     constexpr int KS = KEYREC ? NREC : 1;
-    unsigned char *behind = smem_raw + (size_t)wib * a.lds_per_wave + (((a.w_elems + NREC * S_layout) * sizeof(T) + 7) & ~(size_t)7);
+    unsigned char *behind = smem_raw + (size_t)wib * a.lds_per_wave + ((((FIVE ? 0 : a.w_elems) + NREC * S_layout) * sizeof(T) + 7) & ~(size_t)7);
     unsigned long long *MINKEY = KEYREC ? reinterpret_cast<unsigned long long *>(REC + (GRAD ? (int)kGD : 0))
                                         : reinterpret_cast<unsigned long long *>(behind);
-    int *ARG = reinterpret_cast<int *>(behind + (KEYREC ? 0 : 8 * (size_t)S_layout));
-    unsigned int *QUEUE = reinterpret_cast<unsigned int *>(ARG + S_layout);
+    // deciding boxes: an int array behind the records; five-wave instance: the low half of the records' kD slot during the
+    // exact passes (stride 2 * NREC ints), then 16-bit values in the queue's memory (ARG16)
+    constexpr int AS = FIVE ? 2 * NREC : 1;
+    int *ARG = FIVE ? reinterpret_cast<int *>(REC + (int)kD) : reinterpret_cast<int *>(behind + (KEYREC ? 0 : 8 * (size_t)S_layout));
+    unsigned int *QUEUE = FIVE ? reinterpret_cast<unsigned int *>(behind) : reinterpret_cast<unsigned int *>(ARG + S_layout);
+    short *ARG16 = reinterpret_cast<short *>(QUEUE);
+    T *W = FIVE ? reinterpret_cast<T *>(behind) : base;
+    (void)ARG16;
     MP_PHASE_DECL;
     for (long long cand = (long long)blockIdx.x * wpb + wib; cand < a.n; cand += (long long)gridDim.x * wpb) {
         MP_ARGS_REFRESH();
@@ -604,11 +631,16 @@ __global__ void __launch_bounds__(256, (eval_min_waves<T, GRAD, ROT>())) eval_ke
             const int ngroups = __builtin_amdgcn_readfirstlane(tk.group_count);
             const int n_wide = __builtin_amdgcn_readfirstlane(tk.n_wide);
             for (int k0 = 0; k0 < Sp; k0 += 64) {
-                clearance_chunk<T, ROT, false, false, NREC, KS>(a, boxes, boxes32, a.pairs + __builtin_amdgcn_readfirstlane(tk.spair_begin), groups,
-                                                                ngroups, n_wide, lane, k0, Sp, REC, MINKEY + k0 * KS, ARG + k0, QUEUE);
+                clearance_chunk<T, ROT, false, false, NREC, KS, AS, FIVE>(a, boxes, boxes32, a.pairs + __builtin_amdgcn_readfirstlane(tk.spair_begin), groups,
+                                                                          ngroups, n_wide, lane, k0, Sp, REC, MINKEY + k0 * KS, ARG + k0 * AS, QUEUE);
                 const int k = k0 + lane;
                 if (k < Sp) {
                     const T d = key_to_distance<T>(MINKEY[k * KS]);
+                    if (FIVE) {   // out of the kD slot (same lane) before d goes in; the queue is dead (one chunk)
+                        const int ag = *reinterpret_cast<volatile int *>(&ARG[k * AS]);
+                        ARG16[k] = (short)ag;
+                        __asm__ volatile("" ::: "memory");   // the int read and the double store alias
+                    }
                     RF(k, kD) = d;
                     if (a.dist) a.dist[cand * a.Sp + k] = d;
                 }
@@ -700,12 +732,13 @@ __global__ void __launch_bounds__(256, (eval_min_waves<T, GRAD, ROT>())) eval_ke
         if (mask & (1u << 10))
             for (int j = 0; j < nf; ++j)
                 for (int c3 = 0; c3 < 3; ++c3) {
-                    T e = W[4 * (ff + j) + c3] - tk.ctrl[ff + j][c3];
+                    T e = (FIVE ? a.X[cand * D + 3 * j + c3] : W[4 * (ff + j) + c3]) - tk.ctrl[ff + j][c3];
                     t_via += e * e;
                 }
         if (mask & (1u << 11))
             for (int j = 0; j < Cy; ++j) {
-                T e = W[4 * j + 3] - tk.yaw_ctrl[j];
+                // (five-wave instance: W is gone; the fixed yaw controls contribute exact zeros, like the reference's full sum)
+                T e = (FIVE ? ((j >= 1 && j <= nyf) ? a.X[cand * D + 3 * nf + (j - 1)] : tk.yaw_ctrl[j]) : W[4 * j + 3]) - tk.yaw_ctrl[j];
                 t_ydev += e * e;
             }
         // goal approach alignment: v = P[S-1] - P[first] (telescoped sum of the tail diffs)
@@ -831,7 +864,7 @@ __global__ void __launch_bounds__(256, (eval_min_waves<T, GRAD, ROT>())) eval_ke
                     const int k = a.idx_identity ? s : a.inv_idx[s];
                     if (k >= 0 && k < Sp) {
                         const T gd = RF(k, kGD);
-                        const int arg = ARG[k];
+                        const int arg = FIVE ? (int)ARG16[k] : ARG[k];
                         if (gd != T(0) && arg >= 0) {
                             const BoxRec<T> bx = boxes[arg];
                             if (MODEL == 1) {
@@ -939,9 +972,9 @@ __global__ void __launch_bounds__(256, (eval_min_waves<T, GRAD, ROT>())) eval_ke
                     const int jj = is_pos ? o / 3 : o - 3 * nf;
                     const int comp = is_pos ? o - 3 * jj : 0;
                     if (is_pos) {
-                        if (mask & (1u << 10)) acc += w[10] * T(2) * (W[4 * (ff + jj) + comp] - tk.ctrl[ff + jj][comp]);
+                        if (mask & (1u << 10)) acc += w[10] * T(2) * ((FIVE ? a.X[cand * D + o] : W[4 * (ff + jj) + comp]) - tk.ctrl[ff + jj][comp]);
                     } else {
-                        if (mask & (1u << 11)) acc += w[11] * T(2) * (W[4 * (1 + jj) + 3] - tk.yaw_ctrl[1 + jj]);
+                        if (mask & (1u << 11)) acc += w[11] * T(2) * ((FIVE ? a.X[cand * D + o] : W[4 * (1 + jj) + 3]) - tk.yaw_ctrl[1 + jj]);
                     }
                     gout[o] = acc;
                 }

@@ -794,3 +794,40 @@ def test_scene_query_with_a_tilted_moving_box(oracle_lib):
     d_yaw = s.signed_distance_block(size, pos, (0.0, 0.0, np.sin(0.2), np.cos(0.2)))
     d_gen = s.signed_distance_block(size, pos, (1e-300, 0.0, np.sin(0.2), np.cos(0.2)))
     assert d_gen == pytest.approx(d_yaw, abs=1e-12)
+
+
+@pytest.mark.parametrize("shape", [(50, 64, 1, 2), (13, 64, 2, 2), (30, 33, 1, 3), (120, 48, 3, 6), (2, 16, 1, 2)])
+def test_five_wave_instance_is_bit_identical(shape, native, oracle_lib, monkeypatch):
+    """fp64 gradient launches of fused axis-aligned box scenes with S <= 64 go to the five-waves-per-SIMD instance of
+    eval_kernel (compact LDS slice: waypoint table, 16-bit work queue and 16-bit deciding boxes share 256 bytes; the
+    32-bit deciding-box words live in the records during the exact passes).  Same bits as the standard instance
+    (MP_FIVE_WAVES=0) for cost, gradient, clearances and flags, and both equal the oracle; multi-task batches included."""
+    from motion_planning_amd.problem import build_path_problem
+    from motion_planning_amd.synthetic import random_scene
+
+    n_boxes, S, sub, n_vias = shape
+    rng = np.random.default_rng(100 + S)
+    start, goal = np.array([-1.5, -1.5, 1.5]), np.array([1.5, 1.5, 0.4])
+    probs = []
+    for t in range(3):
+        scene = random_scene(n_boxes, 50 + t, (0.1, 0.6), start, goal)
+        probs.append(build_path_problem(scene, start, goal, native.build_basis, n_vias=n_vias, n_samples_curve=S,
+                                        collision_check_subsample=sub, moving_block_size=(0.9, 0.6, 0.6), start_yaw_deg=0.0,
+                                        goal_yaw_deg=90.0, combined_4d=True, n_yaw_vias=n_vias,
+                                        goal_approach_normals=np.array([[0.0, 0.0, 1.0]]), w_via_dev=0.3, w_yaw_dev=0.01))
+    X = np.vstack([p.x0 + p.sigma0 * rng.normal(size=(70, p.dim)) for p in probs])
+    ref = oracle_lib.evaluate(probs, X, cands_per_task=70)
+    outs = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("MP_FIVE_WAVES", mode)
+        ctx = native.Context(0)
+        ctx.set_problem(probs)
+        ctx.set_cands_per_task(70)
+        outs[mode] = ctx.eval(X, want_grad=True, want_dist=True)
+        nt = ctx.eval(X, want_grad=True, want_terms=False)       # the launch DeviceBatch makes
+        np.testing.assert_array_equal(nt["grad"], outs[mode]["grad"])
+        outs[mode]["cost_nt"] = nt["cost"]      # weighted per lane before the wave sum: differs from the breakdown's sum by rounding
+        ctx.close()
+        _compare(outs[mode], ref, np.float64)
+    for key in ("cost", "cost_nt", "grad", "terms", "dist", "min_clear", "flags"):
+        np.testing.assert_array_equal(outs["1"][key], outs["0"][key], err_msg=key)
