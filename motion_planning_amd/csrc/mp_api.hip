@@ -545,7 +545,7 @@ int launch_eval(mp_ctx *ctx, long long n, const void *X, const int32_t *task_of,
                                 (ext_scratch || ctx->split_mode == 1 ||
                                  (ctx->split_mode < 0 && (ctx->max_task_boxes >= 128 || (c.n_safe > 64 && ctx->max_task_boxes >= 32))));
         const size_t five_block = (size_t)4 * mp::lds_bytes_per_wave_five(c.n_samples);
-        a.five_waves = (sizeof(T) == 8 && grad != nullptr && c.model == MP_MODEL_BOX && !ctx->has_rot && !will_split &&
+        a.five_waves = (sizeof(T) == 8 && grad != nullptr && terms == nullptr && c.model == MP_MODEL_BOX && !ctx->has_rot && !will_split &&
                         c.n_samples <= 64 && ctx->max_task_boxes < 1024 && a.w_elems * (int)sizeof(T) <= 256 &&
                         ((five_block + 1279) / 1280) * 5 <= ctx->max_lds / 1280 && ctx->five_wave_mode != 0) ? 1 : 0;
         if (a.five_waves) a.lds_per_wave = mp::lds_bytes_per_wave_five(c.n_samples);

@@ -496,6 +496,7 @@ __global__ void __launch_bounds__(256, (eval_min_waves<T, GRAD, ROT, WV>())) eva
         T t_safe = T(0), t_pref = T(0), t_reb = T(0), t_gc = T(0), t_gt = T(0), t_ac = T(0), t_acol = T(0);
         T t_via = T(0), t_ydev = T(0), t_gn = T(0), gnx = T(0), gny = T(0), gnz = T(0);
         T mc = Lim<T>::inf();
+        T part = T(0);   // five-wave instance: the weighted per-lane partial sum, folded phase by phase (no breakdown there)
         int Sp = 0, gn_first = 0;
 
         MP_PHASE_INIT;
@@ -560,6 +561,12 @@ __global__ void __launch_bounds__(256, (eval_min_waves<T, GRAD, ROT, WV>())) eva
                 RF(s, kD1x) = (RF(hi, kP0) - RF(lo, kP0)) * sc; RF(s, kD1y) = (RF(hi, kP1) - RF(lo, kP1)) * sc; RF(s, kD1z) = (RF(hi, kP2) - RF(lo, kP2)) * sc;
             }
         }
+        if (FIVE) {   // same order of additions as the cost-only reduction below
+            if (mask & 1u) part += w[0] * t_len;
+            if ((mask & 4u) && S >= 3) part += w[2] * t_ys;
+            if (mask & (1u << 12)) part += w[12] * t_mono;
+            if (mask & (1u << 13)) part += w[13] * t_sched;
+        }
         wave_lds_sync();
         }
         MP_PHASE(1);  // pass 1
@@ -604,6 +611,7 @@ __global__ void __launch_bounds__(256, (eval_min_waves<T, GRAD, ROT, WV>())) eva
             }
         }
         wave_lds_sync();   // the clearance phase reuses the D1 fields (CC SS D)
+        if (FIVE && (mask & 2u) && S >= 3) part += (w[1] * du) * t_curv;
 
         }
         MP_PHASE(2);  // curvature
@@ -722,6 +730,15 @@ __global__ void __launch_bounds__(256, (eval_min_waves<T, GRAD, ROT, WV>())) eva
             }
             if (GRAD) RF(k, kGD) = gd;
         }
+        if (FIVE) {
+            if (mask & (1u << 3)) part += w[3] * t_safe;
+            if (mask & (1u << 4)) part += w[4] * t_pref;
+            if (mask & (1u << 5)) part += w[5] * t_reb;
+            if (mask & (1u << 6)) part += w[6] * t_gc;
+            if (mask & (1u << 7)) part += w[7] * t_gt;
+            if (mask & (1u << 8)) part += w[8] * t_ac;
+            if (mask & (1u << 9)) part += w[9] * t_acol;
+        }
 
         }
         MP_PHASE(4);  // clearance terms
@@ -775,7 +792,7 @@ __global__ void __launch_bounds__(256, (eval_min_waves<T, GRAD, ROT, WV>())) eva
         // ---- reductions over the wave and outputs ----
         T term[kNTerms];
         T jtot = T(0);
-        if (a.terms) {
+        if (!FIVE && a.terms) {
             term[0] = (mask & 1u) ? wave_sum(t_len) : T(0);
             term[1] = ((mask & 2u) && S >= 3) ? wave_sum(t_curv) * du : T(0);
             term[2] = ((mask & 4u) && S >= 3) ? wave_sum(t_ys) : T(0);
@@ -795,20 +812,23 @@ __global__ void __launch_bounds__(256, (eval_min_waves<T, GRAD, ROT, WV>())) eva
             for (int i = 0; i < kNTerms; ++i)
                 if (mask & (1u << i)) jtot = (i == 0) ? w[i] * term[i] : jtot + w[i] * term[i];
         } else {
-            // cost only: weight the per-lane partial sums first, one wave reduction instead of twelve
-            T part = T(0);
-            if (mask & 1u) part += w[0] * t_len;
-            if ((mask & 2u) && S >= 3) part += (w[1] * du) * t_curv;
-            if ((mask & 4u) && S >= 3) part += w[2] * t_ys;
-            if (mask & (1u << 3)) part += w[3] * t_safe;
-            if (mask & (1u << 4)) part += w[4] * t_pref;
-            if (mask & (1u << 5)) part += w[5] * t_reb;
-            if (mask & (1u << 6)) part += w[6] * t_gc;
-            if (mask & (1u << 7)) part += w[7] * t_gt;
-            if (mask & (1u << 8)) part += w[8] * t_ac;
-            if (mask & (1u << 9)) part += w[9] * t_acol;
-            if (mask & (1u << 12)) part += w[12] * t_mono;
-            if (mask & (1u << 13)) part += w[13] * t_sched;
+            // cost only: weight the per-lane partial sums first, one wave reduction instead of twelve.  The order of the
+            // additions is the order in which the phases produce the sums, so that the five-wave instance, which folds
+            // them phase by phase into one register pair, gives the same bits.
+            if (!FIVE) {
+                if (mask & 1u) part += w[0] * t_len;
+                if ((mask & 4u) && S >= 3) part += w[2] * t_ys;
+                if (mask & (1u << 12)) part += w[12] * t_mono;
+                if (mask & (1u << 13)) part += w[13] * t_sched;
+                if ((mask & 2u) && S >= 3) part += (w[1] * du) * t_curv;
+                if (mask & (1u << 3)) part += w[3] * t_safe;
+                if (mask & (1u << 4)) part += w[4] * t_pref;
+                if (mask & (1u << 5)) part += w[5] * t_reb;
+                if (mask & (1u << 6)) part += w[6] * t_gc;
+                if (mask & (1u << 7)) part += w[7] * t_gt;
+                if (mask & (1u << 8)) part += w[8] * t_ac;
+                if (mask & (1u << 9)) part += w[9] * t_acol;
+            }
             jtot = wave_sum(part);
             if (mask & (1u << 10)) jtot += w[10] * t_via;
             if (mask & (1u << 11)) jtot += w[11] * t_ydev;
@@ -820,7 +840,7 @@ __global__ void __launch_bounds__(256, (eval_min_waves<T, GRAD, ROT, WV>())) eva
             if (a.minc) a.minc[cand] = mc;
             if (a.flags) a.flags[cand] = (uint8_t)((mc < T(0) ? 1u : 0u) | (mc >= req ? 2u : 0u));
         }
-        if (a.terms && lane < kNTerms) {
+        if (!FIVE && a.terms && lane < kNTerms) {
             T v = T(0);
 #pragma unroll
             for (int i = 0; i < kNTerms; ++i) v = (lane == i) ? term[i] : v;
