@@ -172,7 +172,8 @@ __host__ __device__ inline int lds_bytes_per_wave(int S, int e, bool grad, int w
     int b = (w_elems + rec_fields(grad) * S) * e;
     b = (b + 7) & ~7;
     if (!key_in_record(grad, e)) b += 8 * S;
-    b += 4 * S + 4 * 128;
+    if (grad) b += 4 * S;   // deciding boxes: gradient launches only
+    b += 4 * 128;
     return (b + 15) & ~15;
 }
 // slice of the five-wave instance (eval_kernel, WV = 5): records + 256 bytes (W / 16-bit queue / 16-bit deciding boxes)
@@ -187,7 +188,8 @@ constexpr int kChunkRec = 7;   // record of clearance_kernel: P0 P1 P2 YW CC SS 
 // (-1: none) and the records' kCC/kSS the (cos, sin) of the sample's yaw.  KS: distance, in keys, between the keys of
 // consecutive slots (1: an array; NREC: the keys are a field of the fp64 records).
 // AS: the same for the deciding-box words (in ints).  Q16: work-queue entries are 16 bits (lane << 10 | box; every task < 1024 boxes).
-template <typename T, int ROT, bool LOCAL, bool SEED, int NREC, int KS = 1, int AS = 1, bool Q16 = false, typename AT>
+// ARGS: keep the deciding box of every sample (the gradient needs it; cost-only launches skip the second atomic and its barriers).
+template <typename T, int ROT, bool LOCAL, bool SEED, int NREC, int KS = 1, int AS = 1, bool Q16 = false, bool ARGS = true, typename AT>
 __device__ __forceinline__ void clearance_chunk(const AT &a, const BoxRec<T> *boxes, const BoxRec32 *boxes32, const BoxPair32 *pairs,
                                                 const BoxRec32 *groups, int ngroups, int n_wide, int lane, int k0, int Sp, T *REC,
                                                 unsigned long long *MINKEY, int *ARG, unsigned int *QUEUE)
@@ -204,7 +206,7 @@ __device__ __forceinline__ void clearance_chunk(const AT &a, const BoxRec<T> *bo
         yaw_rot(rs[kYW], a.trig, c, sn);
         rk[kCC] = c; rk[kSS] = sn;
         MINKEY[lane * KS] = key_init<T>();
-        ARG[lane * AS] = -1;
+        if (ARGS) ARG[lane * AS] = -1;
         px32 = (float)rs[kP0]; py32 = (float)rs[kP1]; pz32 = (float)rs[kP2];
         const float c32 = __builtin_fabsf((float)c), s32 = __builtin_fabsf((float)sn);
         slack = 2e-6f * (__builtin_fabsf(px32) + __builtin_fabsf(py32) + __builtin_fabsf(pz32) +
@@ -287,20 +289,25 @@ __device__ __forceinline__ void clearance_chunk(const AT &a, const BoxRec<T> *bo
                 if (!(po.gsat > T(0)) && !(po.gz > T(0))) atomicAdd(&g_stats[6], 1ull);
             }
 #endif
-            oldk = MINKEY[kk * KS];
+            if (ARGS) oldk = MINKEY[kk * KS];
         }
-        wave_lds_sync();
-        if (act) atomicMin(&MINKEY[kk * KS], key);
-        wave_lds_sync();
-        bool win = false;
-        if (act) {
-            const unsigned long long newk = MINKEY[kk * KS];
-            win = key == newk;
-            if (win && newk < oldk) ARG[kk * AS] = 0x7fffffff;  // strictly better: restart the argmin
+        if (ARGS) {
+            wave_lds_sync();
+            if (act) atomicMin(&MINKEY[kk * KS], key);
+            wave_lds_sync();
+            bool win = false;
+            if (act) {
+                const unsigned long long newk = MINKEY[kk * KS];
+                win = key == newk;
+                if (win && newk < oldk) ARG[kk * AS] = 0x7fffffff;  // strictly better: restart the argmin
+            }
+            wave_lds_sync();
+            if (win) atomicMin(&ARG[kk * AS], bb);  // ties: lowest box index, like a first-minimum scan
+            wave_lds_sync();
+        } else {
+            if (act) atomicMin(&MINKEY[kk * KS], key);
+            wave_lds_sync();
         }
-        wave_lds_sync();
-        if (win) atomicMin(&ARG[kk * AS], bb);  // ties: lowest box index, like a first-minimum scan
-        wave_lds_sync();
         if (valid) {
             const unsigned long long kcur = MINKEY[lane * KS];
             U32 = __builtin_fminf(U32, (float)key_to_sep2<T>(kcur) * (1.0f + 4e-6f));   // never above the seed
@@ -329,7 +336,7 @@ __device__ __forceinline__ void clearance_chunk(const AT &a, const BoxRec<T> *bo
             const T gz = mp_abs(rw[kP2] - eb.cz) - (a.az + eb.hz);
             if (mp_abs(rw[kP0] - eb.cx) <= eb.hx && mp_abs(rw[kP1] - eb.cy) <= eb.hy && gz > T(0)) {
                 MINKEY[lane * KS] = kSepBit | Key<T>::bits(mp_fma(gz, gz, T(0)));   // the slot is still at its initial value
-                ARG[lane * AS] = bi;
+                if (ARGS) ARG[lane * AS] = bi;
                 U32 = __builtin_fminf(U32, (float)key_to_sep2<T>(MINKEY[lane * KS]) * (1.0f + 4e-6f));
                 need = false;
             }
@@ -460,7 +467,7 @@ __global__ void __launch_bounds__(256, (eval_min_waves<T, GRAD, ROT, WV>())) eva
     // exact passes (stride 2 * NREC ints), then 16-bit values in the queue's memory (ARG16)
     constexpr int AS = FIVE ? 2 * NREC : 1;
     int *ARG = FIVE ? reinterpret_cast<int *>(REC + (int)kD) : reinterpret_cast<int *>(behind + (KEYREC ? 0 : 8 * (size_t)S_layout));
-    unsigned int *QUEUE = FIVE ? reinterpret_cast<unsigned int *>(behind) : reinterpret_cast<unsigned int *>(ARG + S_layout);
+    unsigned int *QUEUE = FIVE ? reinterpret_cast<unsigned int *>(behind) : reinterpret_cast<unsigned int *>(ARG + (GRAD ? S_layout : 0));
     short *ARG16 = reinterpret_cast<short *>(QUEUE);
     T *W = FIVE ? reinterpret_cast<T *>(behind) : base;
     (void)ARG16;
@@ -625,7 +632,7 @@ __global__ void __launch_bounds__(256, (eval_min_waves<T, GRAD, ROT, WV>())) eva
             for (int k = lane; k < Sp; k += 64) {
                 const T d = a.pre_d[cand * a.Sp + k];
                 RF(k, kD) = d;
-                ARG[k] = a.pre_arg[cand * a.Sp + k];
+                if (GRAD) ARG[k] = a.pre_arg[cand * a.Sp + k];
                 if (GRAD) {
                     T c, sn;
                     yaw_rot(RF(sample_of(a, k), kYW), a.trig, c, sn);
@@ -639,7 +646,7 @@ __global__ void __launch_bounds__(256, (eval_min_waves<T, GRAD, ROT, WV>())) eva
             const int ngroups = __builtin_amdgcn_readfirstlane(tk.group_count);
             const int n_wide = __builtin_amdgcn_readfirstlane(tk.n_wide);
             for (int k0 = 0; k0 < Sp; k0 += 64) {
-                clearance_chunk<T, ROT, false, false, NREC, KS, AS, FIVE>(a, boxes, boxes32, a.pairs + __builtin_amdgcn_readfirstlane(tk.spair_begin), groups,
+                clearance_chunk<T, ROT, false, false, NREC, KS, AS, FIVE, GRAD>(a, boxes, boxes32, a.pairs + __builtin_amdgcn_readfirstlane(tk.spair_begin), groups,
                                                                           ngroups, n_wide, lane, k0, Sp, REC, MINKEY + k0 * KS, ARG + k0 * AS, QUEUE);
                 const int k = k0 + lane;
                 if (k < Sp) {
@@ -659,7 +666,7 @@ __global__ void __launch_bounds__(256, (eval_min_waves<T, GRAD, ROT, WV>())) eva
                 int arg = -1;
                 const T d = point_distance(RF(s, kP0), RF(s, kP1), RF(s, kP2), boxes, __builtin_amdgcn_readfirstlane(tk.box_count), a.radius, ROT != 0, ROT == 2 ? a.tilt : nullptr, arg);
                 RF(k, kD) = d;
-                ARG[k] = arg;
+                if (GRAD) ARG[k] = arg;
                 if (a.dist) a.dist[cand * a.Sp + k] = d;
             }
         }
