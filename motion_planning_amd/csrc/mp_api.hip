@@ -476,6 +476,9 @@ int launch_eval_p(mp_ctx *ctx, const mp::EvalArgs<T> &args, int wpb, int blocks,
     if constexpr (sizeof(T) == 8 && MODEL == 1 && GRAD && ROT == 0 && !PRE) {
         if (args.five_waves) kern = mp::eval_kernel<T, MODEL, GRAD, ROT, PRE, 5>;
     }
+    if constexpr (sizeof(T) == 8 && MODEL == 1 && !GRAD && ROT == 0 && !PRE) {
+        if (args.five_waves) kern = mp::eval_kernel<T, MODEL, GRAD, ROT, PRE, 6>;
+    }
     if (lds_bytes > 65536) {
         // the opt-in for > 64 KB of dynamic LDS is per kernel variant and device: set once, raise when a larger slice comes
         static std::atomic<int> granted[64];
@@ -544,11 +547,23 @@ int launch_eval(mp_ctx *ctx, long long n, const void *X, const int32_t *task_of,
         const bool will_split = c.model == MP_MODEL_BOX &&
                                 (ext_scratch || ctx->split_mode == 1 ||
                                  (ctx->split_mode < 0 && (ctx->max_task_boxes >= 128 || (c.n_safe > 64 && ctx->max_task_boxes >= 32))));
+        const size_t granules = ctx->max_lds / 1280;
+        auto blocks_fit = [&](size_t block_bytes) { return granules / ((block_bytes + 1279) / 1280); };
+        const bool compact_ok = sizeof(T) == 8 && terms == nullptr && c.model == MP_MODEL_BOX && !ctx->has_rot && !will_split &&
+                                ctx->max_task_boxes < 1024 && a.w_elems * (int)sizeof(T) <= 256 && ctx->five_wave_mode != 0;
         const size_t five_block = (size_t)4 * mp::lds_bytes_per_wave_five(c.n_samples);
-        a.five_waves = (sizeof(T) == 8 && grad != nullptr && terms == nullptr && c.model == MP_MODEL_BOX && !ctx->has_rot && !will_split &&
-                        c.n_samples <= 64 && ctx->max_task_boxes < 1024 && a.w_elems * (int)sizeof(T) <= 256 &&
-                        ((five_block + 1279) / 1280) * 5 <= ctx->max_lds / 1280 && ctx->five_wave_mode != 0) ? 1 : 0;
+        a.five_waves = (compact_ok && grad != nullptr && c.n_samples <= 64 && blocks_fit(five_block) >= 5) ? 1 : 0;
         if (a.five_waves) a.lds_per_wave = mp::lds_bytes_per_wave_five(c.n_samples);
+        // ... and of the fp64 cost-only kernel (WV = 6: six waves per SIMD, no term breakdown, no deciding boxes, any number
+        // of chunks): taken when its smaller slice puts more four-wave blocks on a CU than the standard one (five)
+        if (compact_ok && grad == nullptr) {
+            const size_t cblock = (size_t)4 * mp::lds_bytes_per_wave_compact_cost(c.n_samples);
+            const size_t std_blocks = std::min<size_t>(blocks_fit((size_t)4 * a.lds_per_wave), 5);
+            if (std::min<size_t>(blocks_fit(cblock), 6) > std_blocks) {
+                a.five_waves = 1;
+                a.lds_per_wave = mp::lds_bytes_per_wave_compact_cost(c.n_samples);
+            }
+        }
     }
     const size_t per_wave = (size_t)a.lds_per_wave;
     if (per_wave > ctx->max_lds)

@@ -178,6 +178,8 @@ __host__ __device__ inline int lds_bytes_per_wave(int S, int e, bool grad, int w
 }
 // slice of the five-wave instance (eval_kernel, WV = 5): records + 256 bytes (W / 16-bit queue / 16-bit deciding boxes)
 __host__ __device__ inline int lds_bytes_per_wave_five(int S) { return (15 * 8 * S + 256 + 15) & ~15; }
+// slice of the compact cost-only instance (WV = 6): records (7 fields) + keys + 256 bytes (W / 16-bit queue)
+__host__ __device__ inline int lds_bytes_per_wave_compact_cost(int S) { return (7 * 8 * S + 8 * S + 256 + 15) & ~15; }
 constexpr int kSeedStride = 8;   // the bound of a grouped scene is seeded from the representative of every 8th group
 constexpr int kChunkRec = 7;   // record of clearance_kernel: P0 P1 P2 YW CC SS + 1 (odd)
 
@@ -451,25 +453,30 @@ __global__ void __launch_bounds__(256, (eval_min_waves<T, GRAD, ROT, WV>())) eva
     const int wib = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int wpb = (int)(blockDim.x >> 6);
     const int S_layout = a.S;   // inside the candidate loop every argument is re-read per phase (MP_LOCALS)
-    constexpr bool FIVE = WV == 5;
-    static_assert(!FIVE || (sizeof(T) == 8 && GRAD && MODEL == 1 && !PRE), "the five-wave instance is the fused fp64 gradient kernel");
+    // WV > 0: a compact instance (no term breakdown, W shares the queue's 256 bytes, 16-bit queue entries); FIVE: its
+    // gradient form (deciding boxes in the records / as 16-bit values, one chunk); the cost-only form keeps no deciding boxes
+    constexpr bool COMPACT = WV > 0;
+    constexpr bool FIVE = COMPACT && GRAD;
+    static_assert(!COMPACT || (sizeof(T) == 8 && MODEL == 1 && !PRE), "the compact instances are fused fp64 box-model kernels");
     constexpr int NREC = rec_fields(GRAD);
     T *base = reinterpret_cast<T *>(smem_raw + (size_t)wib * a.lds_per_wave);
-    T *REC = FIVE ? base : base + a.w_elems;
+    T *REC = COMPACT ? base : base + a.w_elems;
 #define RF(s_, f_) REC[(s_) * NREC + (f_)]
     // ordered clearance keys: field kGD of the records (fp64 gradient launches: stride NREC keys) or an array behind them
     constexpr bool KEYREC = key_in_record(GRAD, (int)sizeof(T));
     constexpr int KS = KEYREC ? NREC : 1;
-    unsigned char *behind = smem_raw + (size_t)wib * a.lds_per_wave + ((((FIVE ? 0 : a.w_elems) + NREC * S_layout) * sizeof(T) + 7) & ~(size_t)7);
+    unsigned char *behind = smem_raw + (size_t)wib * a.lds_per_wave + ((((COMPACT ? 0 : a.w_elems) + NREC * S_layout) * sizeof(T) + 7) & ~(size_t)7);
     unsigned long long *MINKEY = KEYREC ? reinterpret_cast<unsigned long long *>(REC + (GRAD ? (int)kGD : 0))
                                         : reinterpret_cast<unsigned long long *>(behind);
     // deciding boxes: an int array behind the records; five-wave instance: the low half of the records' kD slot during the
     // exact passes (stride 2 * NREC ints), then 16-bit values in the queue's memory (ARG16)
     constexpr int AS = FIVE ? 2 * NREC : 1;
     int *ARG = FIVE ? reinterpret_cast<int *>(REC + (int)kD) : reinterpret_cast<int *>(behind + (KEYREC ? 0 : 8 * (size_t)S_layout));
-    unsigned int *QUEUE = FIVE ? reinterpret_cast<unsigned int *>(behind) : reinterpret_cast<unsigned int *>(ARG + (GRAD ? S_layout : 0));
+    // compact cost-only form: MINKEY[S] | QW behind the records
+    unsigned int *QUEUE = FIVE ? reinterpret_cast<unsigned int *>(behind)
+                               : reinterpret_cast<unsigned int *>(ARG + (GRAD ? S_layout : 0));
     short *ARG16 = reinterpret_cast<short *>(QUEUE);
-    T *W = FIVE ? reinterpret_cast<T *>(behind) : base;
+    T *W = COMPACT ? reinterpret_cast<T *>(QUEUE) : base;
     (void)ARG16;
     MP_PHASE_DECL;
     for (long long cand = (long long)blockIdx.x * wpb + wib; cand < a.n; cand += (long long)gridDim.x * wpb) {
@@ -568,7 +575,7 @@ __global__ void __launch_bounds__(256, (eval_min_waves<T, GRAD, ROT, WV>())) eva
                 RF(s, kD1x) = (RF(hi, kP0) - RF(lo, kP0)) * sc; RF(s, kD1y) = (RF(hi, kP1) - RF(lo, kP1)) * sc; RF(s, kD1z) = (RF(hi, kP2) - RF(lo, kP2)) * sc;
             }
         }
-        if (FIVE) {   // same order of additions as the cost-only reduction below
+        if (COMPACT) {   // same order of additions as the cost-only reduction below
             if (mask & 1u) part += w[0] * t_len;
             if ((mask & 4u) && S >= 3) part += w[2] * t_ys;
             if (mask & (1u << 12)) part += w[12] * t_mono;
@@ -618,7 +625,7 @@ __global__ void __launch_bounds__(256, (eval_min_waves<T, GRAD, ROT, WV>())) eva
             }
         }
         wave_lds_sync();   // the clearance phase reuses the D1 fields (CC SS D)
-        if (FIVE && (mask & 2u) && S >= 3) part += (w[1] * du) * t_curv;
+        if (COMPACT && (mask & 2u) && S >= 3) part += (w[1] * du) * t_curv;
 
         }
         MP_PHASE(2);  // curvature
@@ -646,7 +653,7 @@ __global__ void __launch_bounds__(256, (eval_min_waves<T, GRAD, ROT, WV>())) eva
             const int ngroups = __builtin_amdgcn_readfirstlane(tk.group_count);
             const int n_wide = __builtin_amdgcn_readfirstlane(tk.n_wide);
             for (int k0 = 0; k0 < Sp; k0 += 64) {
-                clearance_chunk<T, ROT, false, false, NREC, KS, AS, FIVE, GRAD>(a, boxes, boxes32, a.pairs + __builtin_amdgcn_readfirstlane(tk.spair_begin), groups,
+                clearance_chunk<T, ROT, false, false, NREC, KS, AS, COMPACT, GRAD>(a, boxes, boxes32, a.pairs + __builtin_amdgcn_readfirstlane(tk.spair_begin), groups,
                                                                           ngroups, n_wide, lane, k0, Sp, REC, MINKEY + k0 * KS, ARG + k0 * AS, QUEUE);
                 const int k = k0 + lane;
                 if (k < Sp) {
@@ -737,7 +744,7 @@ __global__ void __launch_bounds__(256, (eval_min_waves<T, GRAD, ROT, WV>())) eva
             }
             if (GRAD) RF(k, kGD) = gd;
         }
-        if (FIVE) {
+        if (COMPACT) {
             if (mask & (1u << 3)) part += w[3] * t_safe;
             if (mask & (1u << 4)) part += w[4] * t_pref;
             if (mask & (1u << 5)) part += w[5] * t_reb;
@@ -756,13 +763,13 @@ __global__ void __launch_bounds__(256, (eval_min_waves<T, GRAD, ROT, WV>())) eva
         if (mask & (1u << 10))
             for (int j = 0; j < nf; ++j)
                 for (int c3 = 0; c3 < 3; ++c3) {
-                    T e = (FIVE ? a.X[cand * D + 3 * j + c3] : W[4 * (ff + j) + c3]) - tk.ctrl[ff + j][c3];
+                    T e = (COMPACT ? a.X[cand * D + 3 * j + c3] : W[4 * (ff + j) + c3]) - tk.ctrl[ff + j][c3];
                     t_via += e * e;
                 }
         if (mask & (1u << 11))
             for (int j = 0; j < Cy; ++j) {
                 // (five-wave instance: W is gone; the fixed yaw controls contribute exact zeros, like the reference's full sum)
-                T e = (FIVE ? ((j >= 1 && j <= nyf) ? a.X[cand * D + 3 * nf + (j - 1)] : tk.yaw_ctrl[j]) : W[4 * j + 3]) - tk.yaw_ctrl[j];
+                T e = (COMPACT ? ((j >= 1 && j <= nyf) ? a.X[cand * D + 3 * nf + (j - 1)] : tk.yaw_ctrl[j]) : W[4 * j + 3]) - tk.yaw_ctrl[j];
                 t_ydev += e * e;
             }
         // goal approach alignment: v = P[S-1] - P[first] (telescoped sum of the tail diffs)
@@ -799,7 +806,7 @@ __global__ void __launch_bounds__(256, (eval_min_waves<T, GRAD, ROT, WV>())) eva
         // ---- reductions over the wave and outputs ----
         T term[kNTerms];
         T jtot = T(0);
-        if (!FIVE && a.terms) {
+        if (!COMPACT && a.terms) {
             term[0] = (mask & 1u) ? wave_sum(t_len) : T(0);
             term[1] = ((mask & 2u) && S >= 3) ? wave_sum(t_curv) * du : T(0);
             term[2] = ((mask & 4u) && S >= 3) ? wave_sum(t_ys) : T(0);
@@ -822,7 +829,7 @@ __global__ void __launch_bounds__(256, (eval_min_waves<T, GRAD, ROT, WV>())) eva
             // cost only: weight the per-lane partial sums first, one wave reduction instead of twelve.  The order of the
             // additions is the order in which the phases produce the sums, so that the five-wave instance, which folds
             // them phase by phase into one register pair, gives the same bits.
-            if (!FIVE) {
+            if (!COMPACT) {
                 if (mask & 1u) part += w[0] * t_len;
                 if ((mask & 4u) && S >= 3) part += w[2] * t_ys;
                 if (mask & (1u << 12)) part += w[12] * t_mono;
@@ -847,7 +854,7 @@ __global__ void __launch_bounds__(256, (eval_min_waves<T, GRAD, ROT, WV>())) eva
             if (a.minc) a.minc[cand] = mc;
             if (a.flags) a.flags[cand] = (uint8_t)((mc < T(0) ? 1u : 0u) | (mc >= req ? 2u : 0u));
         }
-        if (!FIVE && a.terms && lane < kNTerms) {
+        if (!COMPACT && a.terms && lane < kNTerms) {
             T v = T(0);
 #pragma unroll
             for (int i = 0; i < kNTerms; ++i) v = (lane == i) ? term[i] : v;

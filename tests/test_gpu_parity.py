@@ -796,10 +796,10 @@ def test_scene_query_with_a_tilted_moving_box(oracle_lib):
     assert d_gen == pytest.approx(d_yaw, abs=1e-12)
 
 
-@pytest.mark.parametrize("shape", [(50, 64, 1, 2), (13, 64, 2, 2), (30, 33, 1, 3), (120, 48, 3, 6), (2, 16, 1, 2)])
+@pytest.mark.parametrize("shape", [(50, 64, 1, 2), (13, 64, 2, 2), (30, 33, 1, 3), (120, 48, 3, 6), (2, 16, 1, 2), (13, 101, 1, 2), (40, 200, 2, 4)])
 def test_five_wave_instance_is_bit_identical(shape, native, oracle_lib, monkeypatch):
     """fp64 gradient launches of fused axis-aligned box scenes with S <= 64 go to the five-waves-per-SIMD instance of
-    eval_kernel (compact LDS slice: waypoint table, 16-bit work queue and 16-bit deciding boxes share 256 bytes; the
+    eval_kernel, cost-only launches of such scenes (any S) to the compact six-wave instance (compact LDS slice: waypoint table, 16-bit work queue and 16-bit deciding boxes share 256 bytes; the
     32-bit deciding-box words live in the records during the exact passes).  Same bits as the standard instance
     (MP_FIVE_WAVES=0) for cost, gradient, clearances and flags, and both equal the oracle; multi-task batches included."""
     from motion_planning_amd.problem import build_path_problem
@@ -832,6 +832,13 @@ def test_five_wave_instance_is_bit_identical(shape, native, oracle_lib, monkeypa
         np.testing.assert_array_equal(outs[mode]["flags"], ref["flags"])
         np.testing.assert_array_equal(outs[mode]["min_clear"], ref["min_clear"])
         assert H.rel_err(outs[mode]["cost"], ref["cost"]).max() < 1e-9
+        # cost only (a CEM population): the compact six-wave instance when mode is "1" (any number of chunks)
+        co = ctx.eval(X, want_grad=False, want_terms=False, want_dist=True)
+        np.testing.assert_array_equal(co["dist"], ref["dist"])
+        np.testing.assert_array_equal(co["flags"], ref["flags"])
+        np.testing.assert_array_equal(co["min_clear"], ref["min_clear"])
+        outs[mode]["cost_only"] = co["cost"]
         ctx.close()
-    for key in ("cost", "grad", "dist", "min_clear", "flags"):
+    for key in ("cost", "cost_only", "grad", "dist", "min_clear", "flags"):
         np.testing.assert_array_equal(outs["1"][key], outs["0"][key], err_msg=key)
+    np.testing.assert_array_equal(outs["1"]["cost_only"], outs["1"]["cost"])     # same order of additions with and without gradient
