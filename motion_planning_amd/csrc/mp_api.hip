@@ -618,8 +618,10 @@ int launch_eval(mp_ctx *ctx, long long n, const void *X, const int32_t *task_of,
                 hipLaunchKernelGGL((mp::clearance_kernel<T, 2>), dim3(cblocks), dim3(256), clds, ctx->stream, a);
             else if (ctx->has_rot)
                 hipLaunchKernelGGL((mp::clearance_kernel<T, 1>), dim3(cblocks), dim3(256), clds, ctx->stream, a);
-            else
+            else if (grad != nullptr)
                 hipLaunchKernelGGL((mp::clearance_kernel<T, 0>), dim3(cblocks), dim3(256), clds, ctx->stream, a);
+            else   // cost only (a CEM population on a large scene): no deciding boxes
+                hipLaunchKernelGGL((mp::clearance_kernel<T, 0, false>), dim3(cblocks), dim3(256), clds, ctx->stream, a);
             HIP_TRY(ctx, hipGetLastError());
         }
     }

@@ -1034,7 +1034,8 @@ __host__ __device__ inline int clearance_lds_bytes_per_wave(int e)
     return (64 + kChunkRec * 64) * e + 8 * 64 + 4 * 64 + 4 * 128;   // W | REC[64][7] | MINKEY | ARG | QUEUE
 }
 
-template <typename T, int ROT>
+// ARGS: also write the deciding boxes (a gradient launch follows); cost-only launches skip their bookkeeping
+template <typename T, int ROT, bool ARGS = true>
 __global__ void __launch_bounds__(256, (ROT == 2 ? 2 : MP_CLR_WAVES)) clearance_kernel(const EvalArgs<T> a)
 {
     extern __shared__ __align__(16) unsigned char smem_raw[];
@@ -1095,11 +1096,11 @@ __global__ void __launch_bounds__(256, (ROT == 2 ? 2 : MP_CLR_WAVES)) clearance_
             r[kP0] = px; r[kP1] = py; r[kP2] = pz; r[kYW] = yw;
         }
         wave_lds_sync();
-        clearance_chunk<T, ROT, true, true, kChunkRec>(a, boxes, boxes32, a.pairs + __builtin_amdgcn_readfirstlane(tk.spair_begin), groups, ngroups,
+        clearance_chunk<T, ROT, true, true, kChunkRec, 1, 1, false, ARGS>(a, boxes, boxes32, a.pairs + __builtin_amdgcn_readfirstlane(tk.spair_begin), groups, ngroups,
                                                        n_wide, lane, k0, a.Sp, REC, MINKEY, ARG, QUEUE);
         if (k < a.Sp) {
             a.pre_d[cand * a.Sp + k] = key_to_distance<T>(MINKEY[lane]);
-            a.pre_arg[cand * a.Sp + k] = ARG[lane];
+            if (ARGS) a.pre_arg[cand * a.Sp + k] = ARG[lane];
         }
         wave_lds_sync();  // the next unit reuses the slice
     }
