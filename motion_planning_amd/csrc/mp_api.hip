@@ -482,7 +482,13 @@ int launch_eval_p(mp_ctx *ctx, const mp::EvalArgs<T> &args, int wpb, int blocks,
     if (lds_bytes > 65536) {
         // the opt-in for > 64 KB of dynamic LDS is per kernel variant and device: set once, raise when a larger slice comes
         static std::atomic<int> granted[64];
+        static std::atomic<const void *> granted_for[64];   // the instance (standard / compact) the grant was made for
         std::atomic<int> &g = granted[ctx->device & 63];
+        std::atomic<const void *> &gf = granted_for[ctx->device & 63];
+        if (gf.load(std::memory_order_relaxed) != reinterpret_cast<const void *>(kern)) {
+            g.store(0, std::memory_order_relaxed);
+            gf.store(reinterpret_cast<const void *>(kern), std::memory_order_relaxed);
+        }
         if ((int)lds_bytes > g.load(std::memory_order_relaxed)) {
             HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                              (int)lds_bytes));
