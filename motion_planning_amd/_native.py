@@ -87,6 +87,9 @@ def build_basis(n_ctrl: int, degree: int, n_samples: int) -> np.ndarray:
     return M
 
 
+_SMALL_CALL = 512   # rows up to which Context.eval reuses its own output buffers (and their ctypes pointers)
+
+
 def _p(a: Optional[np.ndarray]):
     return None if a is None else a.ctypes.data_as(C.c_void_p)
 
@@ -172,6 +175,7 @@ class Context:
         self._check(self.lib.mp_set_problem(self._h, C.byref(cfg), len(problems), tasks))
         self.problem = p0
         self.n_tasks = len(problems)
+        self._small = None     # output buffers of the small-call path (eval), sized for this problem
 
     def set_cands_per_task(self, n: int) -> None:
         self._check(self.lib.mp_set_cands_per_task(self._h, int(n)))
@@ -196,6 +200,29 @@ class Context:
         n, D = X.shape
         if D != p.dim:
             raise ValueError(f"X must have {p.dim} columns")
+        if n <= _SMALL_CALL and task_of is None:
+            # Small calls (one x from SciPy's Powell, one CEM population) are dominated by Python: ctypes pointer objects cost
+            # ~3.5 us each and a call passes nine.  Outputs go to buffers allocated once per problem, whose pointers are kept;
+            # the caller gets copies of the rows that were written.
+            sm = getattr(self, "_small", None)
+            if sm is None:
+                cap = _SMALL_CALL
+                arrs = {"cost": np.empty(cap, dtype=dt), "terms": np.empty((cap, abi.MP_NTERMS), dtype=dt),
+                        "grad": np.empty((cap, D), dtype=dt), "min_clear": np.empty(cap, dtype=dt),
+                        "flags": np.empty(cap, dtype=np.uint8), "dist": None}
+                sm = self._small = {"arr": arrs, "ptr": {k: _p(v) for k, v in arrs.items()}}
+            arr, ptr = sm["arr"], sm["ptr"]
+            if want_dist and arr["dist"] is None:
+                arr["dist"] = np.empty((_SMALL_CALL, p.n_safe), dtype=dt)
+                ptr["dist"] = _p(arr["dist"])
+            rc = self.lib.mp_eval(self._h, n, C.c_void_p(X.__array_interface__["data"][0]), None, ptr["cost"],
+                                  ptr["terms"] if want_terms else None, ptr["grad"] if want_grad else None, ptr["min_clear"],
+                                  ptr["flags"], ptr["dist"] if want_dist else None, abi.MP_MEM_HOST)
+            if rc != 0:
+                self._check(rc)
+            return {"cost": arr["cost"][:n].copy(), "terms": arr["terms"][:n].copy() if want_terms else None,
+                    "grad": arr["grad"][:n].copy() if want_grad else None, "min_clear": arr["min_clear"][:n].copy(),
+                    "flags": arr["flags"][:n].copy(), "dist": arr["dist"][:n].copy() if want_dist else None}
         cost = np.empty(n, dtype=dt)
         terms = np.empty((n, abi.MP_NTERMS), dtype=dt) if want_terms else None
         grad = np.empty((n, D), dtype=dt) if want_grad else None
