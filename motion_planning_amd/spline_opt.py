@@ -266,33 +266,42 @@ def _cem_optimize_multi(objective, x0, sigma0, seeds, population_size: int = 48,
     populations of the runs still going are evaluated by ONE ``objective`` call.  Run k is, bit for bit, what
     ``_cem_optimize(..., seed=seeds[k])`` returns (same generator, same draw order, same update); only the number of
     evaluator calls changes — max over the runs instead of their sum."""
-    runs = []
-    for sd in seeds:
-        runs.append({"rng": np.random.default_rng(sd), "mean": np.asarray(x0, dtype=float).copy(),
-                     "spread": np.maximum(np.asarray(sigma0, dtype=float), min_sigma), "x": np.asarray(x0, dtype=float).copy(),
-                     "fun": float("inf"), "prev": float("inf"), "nit": 0, "done": False})
-    dim = runs[0]["mean"].size
+    R = len(seeds)
+    rngs = [np.random.default_rng(sd) for sd in seeds]
+    x0 = np.asarray(x0, dtype=float)
+    dim = x0.size
+    mean = np.repeat(x0[None, :], R, axis=0)
+    spread = np.repeat(np.maximum(np.asarray(sigma0, dtype=float), min_sigma)[None, :], R, axis=0)
+    best_x, best = mean.copy(), np.full(R, np.inf)
+    prev = np.full(R, np.inf)
+    nit = np.zeros(R, dtype=int)
+    live = np.ones(R, dtype=bool)
     n_elite = max(2, int(np.ceil(population_size * elite_frac)))
     for _ in range(int(max_iter)):
-        live = [r for r in runs if not r["done"]]
-        if not live:
+        idx = np.nonzero(live)[0]
+        if idx.size == 0:
             break
-        pops = []
-        for r in live:
-            r["nit"] += 1
-            pops.append(r["mean"][None, :] + r["rng"].normal(size=(population_size, dim)) * r["spread"][None, :])
-        values = np.asarray(objective(np.vstack(pops)), dtype=float).reshape(len(live), population_size)
-        for r, population, vals in zip(live, pops, values):
-            lead = int(np.argmin(vals))
-            if vals[lead] < r["fun"]:
-                r["fun"], r["x"] = float(vals[lead]), population[lead].copy()
-            chosen = population[np.argpartition(vals, n_elite - 1)[:n_elite]]
-            r["mean"] = alpha * r["mean"] + (1.0 - alpha) * np.mean(chosen, axis=0)
-            r["spread"] = np.maximum(alpha * r["spread"] + (1.0 - alpha) * (np.std(chosen, axis=0) + min_sigma), min_sigma)
-            if np.abs(r["prev"] - r["fun"]) < tol and float(np.max(r["spread"])) < 0.03:
-                r["done"] = True
-            r["prev"] = r["fun"]
-    return [{"x": r["x"], "fun": r["fun"], "nit": r["nit"], "success": True, "message": "CEM finished"} for r in runs]
+        nit[idx] += 1
+        # the per-run statistics below are the reference's expressions with one leading axis (the run): NumPy reduces
+        # each run's rows in the same order as the single-run code, so the bits are the same (tests/test_host_logic.py)
+        noise = np.stack([rngs[k].normal(size=(population_size, dim)) for k in idx])
+        pops = mean[idx, None, :] + noise * spread[idx, None, :]
+        values = np.asarray(objective(pops.reshape(-1, dim)), dtype=float).reshape(idx.size, population_size)
+        rows = np.arange(idx.size)
+        lead = np.argmin(values, axis=1)
+        lead_val = values[rows, lead]
+        better = lead_val < best[idx]
+        best[idx[better]] = lead_val[better]
+        best_x[idx[better]] = pops[rows[better], lead[better]]
+        elite = np.argpartition(values, n_elite - 1, axis=1)[:, :n_elite]
+        chosen = np.take_along_axis(pops, elite[:, :, None], axis=1)
+        mean[idx] = alpha * mean[idx] + (1.0 - alpha) * np.mean(chosen, axis=1)
+        spread[idx] = np.maximum(alpha * spread[idx] + (1.0 - alpha) * (np.std(chosen, axis=1) + min_sigma), min_sigma)
+        stop = (np.abs(prev[idx] - best[idx]) < tol) & (np.max(spread[idx], axis=1) < 0.03)
+        live[idx[stop]] = False
+        prev[idx] = best[idx]
+    return [{"x": best_x[k].copy(), "fun": float(best[k]), "nit": int(nit[k]), "success": True, "message": "CEM finished"}
+            for k in range(R)]
 
 
 def _refine_with_gradient(value_and_grad: Callable, x: np.ndarray, sigma0: np.ndarray, iters: int = 40, copies: int = 2,
