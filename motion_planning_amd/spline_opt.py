@@ -344,6 +344,7 @@ def _refine_with_gradient(value_and_grad: Callable, x: np.ndarray, sigma0: np.nd
     last = np.zeros((R, D))
     Hinv = np.zeros((R, D, D))          # inverse Hessian estimate in scaled coordinates z = x / sigma0; zero until the first update
     rows = np.arange(R)
+    eye = np.eye(D)
     nit, stalled, best_so_far = 0, 0, float(np.min(cost))
     for _ in range(int(iters)):
         nit += 1
@@ -371,11 +372,15 @@ def _refine_with_gradient(value_and_grad: Callable, x: np.ndarray, sigma0: np.nd
         sv, yv = (new_x - X) / scale[None, :], (new_g - grad) * scale[None, :]
         sy = np.sum(sv * yv, axis=1)
         ok = better & (sy > 1e-12 * np.linalg.norm(sv, axis=1) * np.linalg.norm(yv, axis=1))
-        for r in np.nonzero(ok)[0]:
-            if not Hinv[r].any():
-                Hinv[r] = np.eye(D) * (sy[r] / float(yv[r] @ yv[r]))
-            V = np.eye(D) - np.outer(sv[r], yv[r]) / sy[r]
-            Hinv[r] = V @ Hinv[r] @ V.T + np.outer(sv[r], sv[r]) / sy[r]
+        if ok.any():   # all accepted copies at once (stacked D x D products)
+            u = np.nonzero(ok)[0]
+            s_u, y_u, sy_u = sv[u], yv[u], sy[u][:, None, None]
+            H = Hinv[u]
+            fresh = ~H.reshape(u.size, -1).any(axis=1)
+            if fresh.any():
+                H[fresh] = eye[None, :, :] * (sy[u][fresh] / np.sum(y_u[fresh] * y_u[fresh], axis=1))[:, None, None]
+            V = eye[None, :, :] - s_u[:, :, None] * y_u[:, None, :] / sy_u
+            Hinv[u] = V @ H @ V.transpose(0, 2, 1) + s_u[:, :, None] * s_u[:, None, :] / sy_u
         last = np.where(better[:, None], new_x - X, 0.0)
         X, grad = new_x, new_g
         cost = np.where(better, best, cost)

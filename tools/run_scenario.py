@@ -23,6 +23,7 @@ def main():
                     help="resolved-scenario JSON fixture, or a YAML file in the reference's format")
     ap.add_argument("--method", default=None)
     ap.add_argument("--dtype", default="f64", choices=["f64", "f32"])
+    ap.add_argument("--cprofile", type=int, default=0, help="print the top N functions (cumulative time) of a third, profiled solve")
     args = ap.parse_args()
     path = Path(args.scenarios_file)
     payload = json.loads(path.read_text()) if path.suffix == ".json" else None
@@ -55,6 +56,15 @@ def main():
     (S, vias, info), t_first = solve()       # includes HIP initialisation and the first launch of every kernel
     (S, vias, info), t_warm = solve()
     ev = held["ev"]
+    if args.cprofile:
+        import cProfile
+        import pstats
+
+        pr = cProfile.Profile()
+        pr.enable()
+        solve()
+        pr.disable()
+        pstats.Stats(pr).sort_stats("cumulative").print_stats(args.cprofile)
     print(f"Optimization took {t_warm:.4f} seconds ({ev.n_calls} evaluator calls, {ev.n_evals} objective evaluations; "
           f"first solve of the process, GPU initialisation included: {t_first:.2f} s)")
     print(json.dumps({"config": "BASELINE config 1", "scenario": args.scenario, "method": cfg.get("method", "Powell"),
