@@ -352,7 +352,7 @@ def main():
                         "salu_insts_per_eval": g["SQ_INSTS_SALU"] / N_CAND, "lds_insts_per_eval": g["SQ_INSTS_LDS"] / N_CAND,
                         "valu_issue_util": g["SQ_ACTIVE_INST_VALU"] * 4 / (cycles * 1024),
                         "wave_wait_frac": g["SQ_WAIT_ANY"] / g["SQ_WAVE_CYCLES"],
-                        "launch": "eval_kernel<double, 1, true, 0, false, 5> (the five-waves-per-SIMD instance), 65,536 candidates (this command's batch)",
+                        "launch": "eval_kernel<double, 1, true, 0, false, 5, 1> (the five-waves-per-SIMD instance), 65,536 candidates (this command's batch)",
                         "source": "profiles/r02_pmc/summary.json (rocprofv3 --pmc passes over `bench.py --profile-mode`)"}
             # HBM bytes per launch: FETCH_SIZE (KiB, x2 on gfx950 per MI355X_MICROARCH.md) + WRITE_SIZE (KiB), separate passes
             traffic = int((2.0 * g["FETCH_SIZE"] + g["WRITE_SIZE"]) * 1024)

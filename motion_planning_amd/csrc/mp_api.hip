@@ -73,6 +73,8 @@ struct mp_ctx {
     int max_task_boxes = 0;
     int idx_identity = 0;         // idx_safe is 0, 1, 2, ...
     int split_mode = -1;          // -1 automatic, 0 never, 1 always (MP_SPLIT_CLEARANCE, tuning aid)
+    int wide_min_s = 176;         // the wide instance serves split-mode gradient launches with more samples than this (MP_WIDE_MIN_S)
+    int wide_mode = -1;           // -1 automatic, 0 never (MP_WIDE=0, tuning aid / A-B of the wide split-mode instance)
     int five_wave_mode = -1;      // -1 automatic, 0 never (MP_FIVE_WAVES=0, tuning aid / A-B of the five-wave gradient instance)
     int cem_graph = 1;            // replay the CEM generations from a captured HIP graph (MP_CEM_GRAPH=0 turns it off)
 
@@ -479,6 +481,10 @@ int launch_eval_p(mp_ctx *ctx, const mp::EvalArgs<T> &args, int wpb, int blocks,
     if constexpr (sizeof(T) == 8 && MODEL == 1 && !GRAD && ROT == 0 && !PRE) {
         if (args.five_waves) kern = mp::eval_kernel<T, MODEL, GRAD, ROT, PRE, 6>;
     }
+    if constexpr (sizeof(T) == 8 && MODEL == 1 && ROT < 2 && PRE && GRAD) {
+        if (args.wide == 4) kern = mp::eval_kernel<T, MODEL, GRAD, ROT, PRE, 0, 4>;
+        if (args.wide == 3) kern = mp::eval_kernel<T, MODEL, GRAD, ROT, PRE, 0, 3>;
+    }
     if (lds_bytes > 65536) {
         // the opt-in for > 64 KB of dynamic LDS is per kernel variant and device: set once, raise when a larger slice comes
         static std::atomic<int> granted[64];
@@ -631,10 +637,24 @@ int launch_eval(mp_ctx *ctx, long long n, const void *X, const int32_t *task_of,
             HIP_TRY(ctx, hipGetLastError());
         }
     }
+    // Wide instance (mp_kernels.hpp, NW = 3 / 4) for split-mode fp64 gradient launches without the term breakdown on long
+    // trajectories: there the slice of a candidate leaves room for one or two waves per SIMD; one candidate per three- or
+    // four-wave block keeps that many waves per slice busy.  Measured (B=50, cost+grad, standard -> wide): S=129 0.548 -> 0.583 ms,
+    // S=160 0.586 -> 0.611, S=192 0.360 -> 0.320 (four waves: 0.340), S=256 0.587 -> 0.433, S=512 0.788 -> 0.437; two-wave
+    // blocks at S=101 lose (0.371 -> 0.410), and cost-only launches lose 1-5 % (their slices are half the size).
+    size_t lds_launch = lds_bytes;
+    const int nw = std::min(4, std::max(3, (c.n_samples + 63) / 64));
+    if (sizeof(T) == 8 && a.pre_d && grad != nullptr && terms == nullptr && ctx->has_rot < 2 && c.n_samples > ctx->wide_min_s &&
+        3 * c.n_free + c.n_yaw_free <= 64 && ctx->wide_mode != 0 && per_wave + nw * 64 * sizeof(T) <= ctx->max_lds) {
+        a.wide = nw;
+        wpb = nw;
+        lds_launch = per_wave + nw * 64 * sizeof(T);
+        blocks = (int)std::min<long long>(n, (long long)ctx->num_cu * 16);
+    }
     const bool g = grad != nullptr;
     if (c.model == MP_MODEL_BOX)
-        return g ? launch_eval_k<T, 1, true>(ctx, a, wpb, blocks, lds_bytes)
-                 : launch_eval_k<T, 1, false>(ctx, a, wpb, blocks, lds_bytes);
+        return g ? launch_eval_k<T, 1, true>(ctx, a, wpb, blocks, lds_launch)
+                 : launch_eval_k<T, 1, false>(ctx, a, wpb, blocks, lds_launch);
     return g ? launch_eval_k<T, 0, true>(ctx, a, wpb, blocks, lds_bytes)
              : launch_eval_k<T, 0, false>(ctx, a, wpb, blocks, lds_bytes);
 }
@@ -796,6 +816,8 @@ int mp_create(int device_id, int dtype, mp_ctx **out)
     mp_ctx *ctx = new mp_ctx();
     ctx->device = device_id;
     if (const char *sm = std::getenv("MP_SPLIT_CLEARANCE")) ctx->split_mode = std::atoi(sm) != 0 ? 1 : 0;
+    if (const char *wm = std::getenv("MP_WIDE")) ctx->wide_mode = std::atoi(wm) != 0 ? -1 : 0;
+    if (const char *ws = std::getenv("MP_WIDE_MIN_S")) ctx->wide_min_s = std::atoi(ws);
     if (const char *fw = std::getenv("MP_FIVE_WAVES")) ctx->five_wave_mode = std::atoi(fw) != 0 ? -1 : 0;
     if (const char *cg = std::getenv("MP_CEM_GRAPH")) ctx->cem_graph = std::atoi(cg) != 0 ? 1 : 0;
     ctx->dtype = dtype;

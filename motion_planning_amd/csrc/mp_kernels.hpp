@@ -16,6 +16,9 @@ namespace mp {
 #ifndef MP_CLR_WAVES
 #define MP_CLR_WAVES 6   // waves per SIMD clearance_kernel is register-budgeted for (measured: 4 0.934, 5 0.847, 6 0.792, 7 0.794, 8 0.815 ms)
 #endif
+#ifndef MP_WIDE_WAVES
+#define MP_WIDE_WAVES 4   // waves per SIMD the wide split-mode instance (eval_kernel, NW = 4) is register-budgeted for
+#endif
 #ifndef MP_COST64_WAVES
 #define MP_COST64_WAVES 5   // waves per SIMD the fp64 cost-only kernels are register-budgeted for (<= 96 VGPRs)
 #endif
@@ -65,6 +68,7 @@ template <typename T> struct EvalArgs {
     int lds_per_wave;  // bytes
     int w_elems;       // elements of the waypoint table W in front of the records
     int five_waves;    // 1: the launch uses the five-waves-per-SIMD instance and its compact LDS slice (see eval_kernel, WV)
+    int wide;          // > 1: the launch uses the wide instance (one candidate per block of `wide` waves; see eval_kernel, NW)
     int n_tasks;
     T w[kNTerms];
     T req, pref, appr_tgt, goal_tgt, radius, ax, ay, az;
@@ -399,9 +403,10 @@ __device__ __forceinline__ void clearance_chunk(const AT &a, const BoxRec<T> *bo
 // Waves per SIMD the register budget is sized for: fp64 gradient kernels 4 (122 VGPRs), fp64 cost-only kernels 5 (95; round 1 needed 168
 // for the gradient kernels: 3 waves), fp32 kernels 7 (72 VGPRs).  No scratch memory except one 8-byte accumulator per
 // lane in the fused fp64 cost-only box instances (profiles/r02_kernel_resources.txt).
-template <typename T, bool GRAD, int ROT = 0, int WV = 0> constexpr int eval_min_waves()
+template <typename T, bool GRAD, int ROT = 0, int WV = 0, int NW = 1> constexpr int eval_min_waves()
 {
     if (WV > 0) return WV;
+    if (NW > 1) return MP_WIDE_WAVES;
     return ROT == 2 ? 2   // the tilt routine is a real call: its registers count too
                     : (sizeof(T) == 4 ? MP_F32_WAVES : (GRAD ? MP_GRAD64_WAVES : MP_COST64_WAVES));
 }
@@ -413,8 +418,8 @@ template <typename T, bool GRAD, int ROT = 0, int WV = 0> constexpr int eval_min
 //     the deciding boxes as 16-bit values; the closed-form terms read the free waypoints from x itself;
 //   * during the exact passes the 32-bit deciding-box words (they need 32-bit LDS atomics) live in the low half of the
 //     records' kD slot, which is free until the clearance is written there at the end of the chunk.
-template <typename T, int MODEL, bool GRAD, int ROT, bool PRE, int WV = 0>
-__global__ void __launch_bounds__(256, (eval_min_waves<T, GRAD, ROT, WV>())) eval_kernel(const EvalArgs<T> a_by_value)
+template <typename T, int MODEL, bool GRAD, int ROT, bool PRE, int WV = 0, int NW = 1>
+__global__ void __launch_bounds__(256, (eval_min_waves<T, GRAD, ROT, WV, NW>())) eval_kernel(const EvalArgs<T> a_by_value)
 {
     // The arguments are read through the kernel-argument segment pointer (the explicit arguments start at offset 0),
     // re-derived behind an opaque barrier at the start of every phase of the candidate loop (MP_ARGS_REFRESH).  Read as
@@ -458,14 +463,25 @@ __global__ void __launch_bounds__(256, (eval_min_waves<T, GRAD, ROT, WV>())) eva
     constexpr bool COMPACT = WV > 0;
     constexpr bool FIVE = COMPACT && GRAD;
     static_assert(!COMPACT || (sizeof(T) == 8 && MODEL == 1 && !PRE), "the compact instances are fused fp64 box-model kernels");
+    // NW > 1: the wide instance (split mode, long trajectories): ONE candidate per block, sample s on lane s mod 64 of wave
+    // (s / 64) mod NW, so that a 256-sample trajectory keeps four waves busy per 32 KB slice instead of one; the phases
+    // are separated by block barriers, sums cross the waves through RED (NW x 64 values behind the slice)
+    constexpr bool WIDE = NW > 1;
+    constexpr bool FOLD = COMPACT || WIDE;   // no term breakdown: the weighted partial sums are folded into `part` phase by phase
+    static_assert(!WIDE || (PRE && MODEL == 1 && WV == 0 && GRAD), "the wide instance is a split-mode box-model gradient kernel");
+    const int wv = WIDE ? wib : 0;       // which 64-sample column of every trip this wave takes
+    const int slice = WIDE ? 0 : wib;
+#define MP_CAND_SYNC() do { if constexpr (NW > 1) __syncthreads(); else wave_lds_sync(); } while (0)
     constexpr int NREC = rec_fields(GRAD);
-    T *base = reinterpret_cast<T *>(smem_raw + (size_t)wib * a.lds_per_wave);
+    T *base = reinterpret_cast<T *>(smem_raw + (size_t)slice * a.lds_per_wave);
+    T *RED = reinterpret_cast<T *>(smem_raw + a.lds_per_wave);
+    (void)RED;
     T *REC = COMPACT ? base : base + a.w_elems;
 #define RF(s_, f_) REC[(s_) * NREC + (f_)]
     // ordered clearance keys: field kGD of the records (fp64 gradient launches: stride NREC keys) or an array behind them
     constexpr bool KEYREC = key_in_record(GRAD, (int)sizeof(T));
     constexpr int KS = KEYREC ? NREC : 1;
-    unsigned char *behind = smem_raw + (size_t)wib * a.lds_per_wave + ((((COMPACT ? 0 : a.w_elems) + NREC * S_layout) * sizeof(T) + 7) & ~(size_t)7);
+    unsigned char *behind = smem_raw + (size_t)slice * a.lds_per_wave + ((((COMPACT ? 0 : a.w_elems) + NREC * S_layout) * sizeof(T) + 7) & ~(size_t)7);
     unsigned long long *MINKEY = KEYREC ? reinterpret_cast<unsigned long long *>(REC + (GRAD ? (int)kGD : 0))
                                         : reinterpret_cast<unsigned long long *>(behind);
     // deciding boxes: an int array behind the records; five-wave instance: the low half of the records' kD slot during the
@@ -479,7 +495,8 @@ __global__ void __launch_bounds__(256, (eval_min_waves<T, GRAD, ROT, WV>())) eva
     T *W = COMPACT ? reinterpret_cast<T *>(QUEUE) : base;
     (void)ARG16;
     MP_PHASE_DECL;
-    for (long long cand = (long long)blockIdx.x * wpb + wib; cand < a.n; cand += (long long)gridDim.x * wpb) {
+    for (long long cand = WIDE ? (long long)blockIdx.x : (long long)blockIdx.x * wpb + wib; cand < a.n;
+         cand += WIDE ? (long long)gridDim.x : (long long)gridDim.x * wpb) {
         MP_ARGS_REFRESH();
         long long tl;
         if (a.group_size > 0) {
@@ -520,7 +537,7 @@ __global__ void __launch_bounds__(256, (eval_min_waves<T, GRAD, ROT, WV>())) eva
         // ---- waypoint table W[j][0..2] = position rows, W[j][3] = yaw controls ----
         {
             const int rows = C > Cy ? C : Cy;
-            for (int i = lane; i < rows * 4; i += 64) {
+            for (int i = lane + 64 * wv; i < rows * 4; i += 64 * NW) {
                 const int j = i >> 2, col = i & 3;
                 T v = T(0);
                 if (col < 3) {
@@ -531,15 +548,15 @@ __global__ void __launch_bounds__(256, (eval_min_waves<T, GRAD, ROT, WV>())) eva
                 W[i] = v;
             }
         }
-        wave_lds_sync();
+        MP_CAND_SYNC();
 
         // ---- spline samples Q = M W (fixed fma chain over the waypoints) ----
-        for (int s = lane; s < S; s += 64) {
+        for (int s = lane + 64 * wv; s < S; s += 64 * NW) {
             T px, py, pz, yw;
             spline_sample(M + (size_t)s * C, My + (size_t)s * Cy, C, Cy, W, px, py, pz, yw);
             RF(s, kP0) = px; RF(s, kP1) = py; RF(s, kP2) = pz; RF(s, kYW) = yw;
         }
-        wave_lds_sync();
+        MP_CAND_SYNC();
 
         }
         MP_PHASE(0);  // waypoints + spline
@@ -548,7 +565,7 @@ __global__ void __launch_bounds__(256, (eval_min_waves<T, GRAD, ROT, WV>())) eva
         MP_LOCALS;
         // ---- per-sample geometric terms, pass 1 ----
         const T y0 = tk.yaw_ctrl[0], y1 = tk.yaw_ctrl[Cy - 1];
-        for (int s = lane; s < S; s += 64) {
+        for (int s = lane + 64 * wv; s < S; s += 64 * NW) {
             const T px = RF(s, kP0), py = RF(s, kP1), pz = RF(s, kP2), yw = RF(s, kYW);
             if (s + 1 < S) {
                 T ex = RF(s + 1, kP0) - px, ey = RF(s + 1, kP1) - py, ez = RF(s + 1, kP2) - pz;
@@ -575,13 +592,13 @@ __global__ void __launch_bounds__(256, (eval_min_waves<T, GRAD, ROT, WV>())) eva
                 RF(s, kD1x) = (RF(hi, kP0) - RF(lo, kP0)) * sc; RF(s, kD1y) = (RF(hi, kP1) - RF(lo, kP1)) * sc; RF(s, kD1z) = (RF(hi, kP2) - RF(lo, kP2)) * sc;
             }
         }
-        if (COMPACT) {   // same order of additions as the cost-only reduction below
+        if (FOLD) {   // same order of additions as the cost-only reduction below
             if (mask & 1u) part += w[0] * t_len;
             if ((mask & 4u) && S >= 3) part += w[2] * t_ys;
             if (mask & (1u << 12)) part += w[12] * t_mono;
             if (mask & (1u << 13)) part += w[13] * t_sched;
         }
-        wave_lds_sync();
+        MP_CAND_SYNC();
         }
         MP_PHASE(1);  // pass 1
         MP_ARGS_REFRESH();
@@ -590,7 +607,7 @@ __global__ void __launch_bounds__(256, (eval_min_waves<T, GRAD, ROT, WV>())) eva
         // ---- curvature, pass 2 (second np.gradient) ----
         if ((mask & (1u << 1)) && S >= 3) {
             const T eps = T(1e-9);
-            for (int s = lane; s < S; s += 64) {
+            for (int s = lane + 64 * wv; s < S; s += 64 * NW) {
                 const T v1x = RF(s, kD1x), v1y = RF(s, kD1y), v1z = RF(s, kD1z);
                 const int lo = s == 0 ? 0 : s - 1, hi = s == S - 1 ? s : s + 1;
                 const T sc = (s == 0 || s == S - 1) ? inv_du : inv_h2;
@@ -624,8 +641,8 @@ __global__ void __launch_bounds__(256, (eval_min_waves<T, GRAD, ROT, WV>())) eva
                 }
             }
         }
-        wave_lds_sync();   // the clearance phase reuses the D1 fields (CC SS D)
-        if (COMPACT && (mask & 2u) && S >= 3) part += (w[1] * du) * t_curv;
+        MP_CAND_SYNC();   // the clearance phase reuses the D1 fields (CC SS D)
+        if (FOLD && (mask & 2u) && S >= 3) part += (w[1] * du) * t_curv;
 
         }
         MP_PHASE(2);  // curvature
@@ -636,7 +653,7 @@ __global__ void __launch_bounds__(256, (eval_min_waves<T, GRAD, ROT, WV>())) eva
         Sp = a.Sp;
         if (MODEL == 1 && PRE) {
             // split mode: the clearance profile was computed by clearance_kernel (one wave per 64-sample chunk)
-            for (int k = lane; k < Sp; k += 64) {
+            for (int k = lane + 64 * wv; k < Sp; k += 64 * NW) {
                 const T d = a.pre_d[cand * a.Sp + k];
                 RF(k, kD) = d;
                 if (GRAD) ARG[k] = a.pre_arg[cand * a.Sp + k];
@@ -668,7 +685,7 @@ __global__ void __launch_bounds__(256, (eval_min_waves<T, GRAD, ROT, WV>())) eva
                 }
             }
         } else {
-            for (int k = lane; k < Sp; k += 64) {
+            for (int k = lane + 64 * wv; k < Sp; k += 64 * NW) {
                 const int s = sample_of(a, k);
                 int arg = -1;
                 const T d = point_distance(RF(s, kP0), RF(s, kP1), RF(s, kP2), boxes, __builtin_amdgcn_readfirstlane(tk.box_count), a.radius, ROT != 0, ROT == 2 ? a.tilt : nullptr, arg);
@@ -677,7 +694,7 @@ __global__ void __launch_bounds__(256, (eval_min_waves<T, GRAD, ROT, WV>())) eva
                 if (a.dist) a.dist[cand * a.Sp + k] = d;
             }
         }
-        wave_lds_sync();
+        MP_CAND_SYNC();
         if (last_cond && Sp >= 2) {  // P[::k] + conditional last sample (spline_opt.py:802-805)
             const int sa = sample_of(a, Sp - 2), sb = S - 1;
             bool close = mp_abs(RF(sa, kP0) - RF(sb, kP0)) <= T(1e-8) + T(1e-5) * mp_abs(RF(sb, kP0));
@@ -692,7 +709,7 @@ __global__ void __launch_bounds__(256, (eval_min_waves<T, GRAD, ROT, WV>())) eva
         {
         MP_LOCALS;
         // ---- clearance terms (and d cost / d d_k) ----
-        for (int k = lane; k < Sp; k += 64) {
+        for (int k = lane + 64 * wv; k < Sp; k += 64 * NW) {
             const T d = RF(k, kD);
             mc = d < mc ? d : mc;
             T gd = T(0);
@@ -744,7 +761,7 @@ __global__ void __launch_bounds__(256, (eval_min_waves<T, GRAD, ROT, WV>())) eva
             }
             if (GRAD) RF(k, kGD) = gd;
         }
-        if (COMPACT) {
+        if (FOLD) {
             if (mask & (1u << 3)) part += w[3] * t_safe;
             if (mask & (1u << 4)) part += w[4] * t_pref;
             if (mask & (1u << 5)) part += w[5] * t_reb;
@@ -806,7 +823,21 @@ __global__ void __launch_bounds__(256, (eval_min_waves<T, GRAD, ROT, WV>())) eva
         // ---- reductions over the wave and outputs ----
         T term[kNTerms];
         T jtot = T(0);
-        if (!COMPACT && a.terms) {
+        if constexpr (WIDE) {
+            // per-wave sum and minimum, then the waves' values combined in wave order (every thread ends up with the totals)
+            const T ps = wave_sum(part), pm = wave_min(mc);
+            if (lane == 0) { RED[wv * 2] = ps; RED[wv * 2 + 1] = pm; }
+            __syncthreads();
+            jtot = RED[0];
+            mc = RED[1];
+            for (int v = 1; v < NW; ++v) {
+                jtot += RED[v * 2];
+                mc = lane_min(mc, RED[v * 2 + 1]);
+            }
+            if (mask & (1u << 10)) jtot += w[10] * t_via;
+            if (mask & (1u << 11)) jtot += w[11] * t_ydev;
+            if (mask & (1u << 14)) jtot += w[14] * t_gn;
+        } else if (!COMPACT && a.terms) {
             term[0] = (mask & 1u) ? wave_sum(t_len) : T(0);
             term[1] = ((mask & 2u) && S >= 3) ? wave_sum(t_curv) * du : T(0);
             term[2] = ((mask & 4u) && S >= 3) ? wave_sum(t_ys) : T(0);
@@ -848,13 +879,13 @@ __global__ void __launch_bounds__(256, (eval_min_waves<T, GRAD, ROT, WV>())) eva
             if (mask & (1u << 11)) jtot += w[11] * t_ydev;
             if (mask & (1u << 14)) jtot += w[14] * t_gn;
         }
-        mc = wave_min(mc);
-        if (lane == 0) {
+        if constexpr (!WIDE) mc = wave_min(mc);
+        if (lane == 0 && wv == 0) {
             a.cost[cand] = jtot;
             if (a.minc) a.minc[cand] = mc;
             if (a.flags) a.flags[cand] = (uint8_t)((mc < T(0) ? 1u : 0u) | (mc >= req ? 2u : 0u));
         }
-        if (!COMPACT && a.terms && lane < kNTerms) {
+        if (!FOLD && a.terms && lane < kNTerms) {
             T v = T(0);
 #pragma unroll
             for (int i = 0; i < kNTerms; ++i) v = (lane == i) ? term[i] : v;
@@ -864,7 +895,7 @@ __global__ void __launch_bounds__(256, (eval_min_waves<T, GRAD, ROT, WV>())) eva
         }
         if (GRAD) {
             MP_PHASE(6);  // reductions + outputs
-            wave_lds_sync();
+            MP_CAND_SYNC();
             MP_PHASE(7);  // grad: clearance chain
             MP_ARGS_REFRESH();
             {
@@ -873,7 +904,7 @@ __global__ void __launch_bounds__(256, (eval_min_waves<T, GRAD, ROT, WV>())) eva
             // with the transposed np.gradient coefficients of row s (ends one-sided, inside central).
             const bool curv = (mask & 2u) && S >= 3;
             if (curv) {
-                for (int s = lane; s < S; s += 64) {
+                for (int s = lane + 64 * wv; s < S; s += 64 * NW) {
                     const T cm = s == 1 ? inv_du : ((s >= 2) ? inv_h2 : T(0));
                     const T cp = s == S - 2 ? -inv_du : ((s <= S - 3) ? -inv_h2 : T(0));
                     const T c0 = s == 0 ? -inv_du : (s == S - 1 ? inv_du : T(0));
@@ -883,7 +914,7 @@ __global__ void __launch_bounds__(256, (eval_min_waves<T, GRAD, ROT, WV>())) eva
                     RF(s, kA1z) = RF(s, kA1z) + (cm * RF(lo, kA2z) + c0 * RF(s, kA2z) + cp * RF(hi, kA2z));
                 }
             }
-            wave_lds_sync();
+            MP_CAND_SYNC();
             }
             MP_PHASE(8);  // grad: curvature transpose
             MP_ARGS_REFRESH();
@@ -892,7 +923,7 @@ __global__ void __launch_bounds__(256, (eval_min_waves<T, GRAD, ROT, WV>())) eva
             const bool curv = (mask & 2u) && S >= 3;
             const T y0 = tk.yaw_ctrl[0], y1 = tk.yaw_ctrl[Cy - 1];
             // (3) gather every contribution to gP[s], gyaw[s]
-            for (int s = lane; s < S; s += 64) {
+            for (int s = lane + 64 * wv; s < S; s += 64 * NW) {
                 T gx = T(0), gy = T(0), gz = T(0), gw = T(0);
                 {   // clearance chain: d cost/d d_k * d d_k/d(P, yaw) of the collision sample taken at this spline sample
                     const int k = a.idx_identity ? s : a.inv_idx[s];
@@ -962,7 +993,7 @@ __global__ void __launch_bounds__(256, (eval_min_waves<T, GRAD, ROT, WV>())) eva
                 }
                 RF(s, kGX) = gx; RF(s, kGY) = gy; RF(s, kGZ) = gz; RF(s, kGW) = gw;   // slots dead by now (see RecField)
             }
-            wave_lds_sync();
+            MP_CAND_SYNC();
             }
             MP_PHASE(9);  // grad: gather
             MP_ARGS_REFRESH();
@@ -985,7 +1016,7 @@ __global__ void __launch_bounds__(256, (eval_min_waves<T, GRAD, ROT, WV>())) eva
                     const int ld = is_pos ? C : Cy;
                     // eight (M, g) pairs fetched per trip, then the same in-order fma chain (a one-at-a-time loop
                     // waits for every load in turn)
-                    for (int b0 = sg8; b0 < S; b0 += 64) {
+                    for (int b0 = sg8 + 64 * wv; b0 < S; b0 += 64 * NW) {
                         T mv[8], gv[8];
 #pragma unroll
                         for (int u = 0; u < 8; ++u) {
@@ -1001,7 +1032,9 @@ __global__ void __launch_bounds__(256, (eval_min_waves<T, GRAD, ROT, WV>())) eva
                 acc += dpp_mov<0xB1, 0xf, true>(acc);   // quad_perm [1,0,3,2]
                 acc += dpp_mov<0x4E, 0xf, true>(acc);   // quad_perm [2,3,0,1]
                 acc += dpp_mov<0x141, 0xf, true>(acc);  // row_half_mirror: the other quad of this group of 8
-                if (o < D && sg8 == 0) {
+                if constexpr (WIDE) {
+                    if (o < D && sg8 == 0) RED[wv * 64 + o] = acc;   // this wave's share of the samples
+                } else if (o < D && sg8 == 0) {
                     const bool is_pos = o < 3 * nf;
                     const int jj = is_pos ? o / 3 : o - 3 * nf;
                     const int comp = is_pos ? o - 3 * jj : 0;
@@ -1013,10 +1046,27 @@ __global__ void __launch_bounds__(256, (eval_min_waves<T, GRAD, ROT, WV>())) eva
                     gout[o] = acc;
                 }
             }
+            if constexpr (WIDE) {   // the waves' shares added in wave order, one output per thread (D <= 64)
+                __syncthreads();
+                const int o = lane + 64 * wv;
+                if (o < D) {
+                    T acc = RED[o];
+                    for (int v = 1; v < NW; ++v) acc += RED[v * 64 + o];
+                    const bool is_pos = o < 3 * nf;
+                    const int jj = is_pos ? o / 3 : o - 3 * nf;
+                    const int comp = is_pos ? o - 3 * jj : 0;
+                    if (is_pos) {
+                        if (mask & (1u << 10)) acc += w[10] * T(2) * (W[4 * (ff + jj) + comp] - tk.ctrl[ff + jj][comp]);
+                    } else {
+                        if (mask & (1u << 11)) acc += w[11] * T(2) * (W[4 * (1 + jj) + 3] - tk.yaw_ctrl[1 + jj]);
+                    }
+                    gout[o] = acc;
+                }
+            }
             }
         }
         MP_PHASE(10);  // grad: M^T g (or, cost only: reductions + outputs)
-        wave_lds_sync();  // the next candidate reuses the slice
+        MP_CAND_SYNC();  // the next candidate reuses the slice
     }
     MP_PHASE_FLUSH;
 }
@@ -1024,6 +1074,7 @@ __global__ void __launch_bounds__(256, (eval_min_waves<T, GRAD, ROT, WV>())) eva
 #undef a
 #undef MP_ARGS_REFRESH
 #undef MP_LOCALS
+#undef MP_CAND_SYNC
 
 // ---- split mode: the clearance profile on its own, one wave per (candidate, 64-sample chunk) --------------
 // With many samples per trajectory the LDS slice of eval_kernel leaves room for very few waves per CU, while

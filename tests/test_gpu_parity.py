@@ -818,6 +818,7 @@ def test_five_wave_instance_is_bit_identical(shape, native, oracle_lib, monkeypa
     X = np.vstack([p.x0 + p.sigma0 * rng.normal(size=(70, p.dim)) for p in probs])
     ref = oracle_lib.evaluate(probs, X, cands_per_task=70)
     outs = {}
+    monkeypatch.setenv("MP_WIDE", "0")   # (S = 200 in split mode would take the wide instance: test_wide_instance_matches_the_standard_one)
     for mode in ("1", "0"):
         monkeypatch.setenv("MP_FIVE_WAVES", mode)
         ctx = native.Context(0)
@@ -842,3 +843,54 @@ def test_five_wave_instance_is_bit_identical(shape, native, oracle_lib, monkeypa
     for key in ("cost", "cost_only", "grad", "dist", "min_clear", "flags"):
         np.testing.assert_array_equal(outs["1"][key], outs["0"][key], err_msg=key)
     np.testing.assert_array_equal(outs["1"]["cost_only"], outs["1"]["cost"])     # same order of additions with and without gradient
+
+
+@pytest.mark.parametrize("shape", [(50, 256, 1, 2, False), (40, 129, 1, 3, False), (150, 200, 2, 6, False), (33, 300, 3, 2, True),
+                                   (60, 193, 1, 4, True), (45, 185, 1, 3, False)])
+def test_wide_instance_matches_the_standard_one(shape, native, oracle_lib, monkeypatch):
+    """Split-mode fp64 gradient launches without the term breakdown on trajectories of more than 176 samples go to the wide
+    instance of eval_kernel (one candidate per three- or four-wave block, sums combined across the waves through LDS).
+    Clearance profile, min clearance and flags are the oracle's bits and the standard instance's (MP_WIDE=0); cost and
+    gradient differ from the standard instance by the order of additions only (1e-12) and meet the oracle's bar.
+    S = 129 stays on the standard instance (both modes the same launch)."""
+    from motion_planning_amd.problem import build_path_problem
+    from motion_planning_amd.synthetic import random_scene
+
+    n_boxes, S, sub, n_vias, rotated = shape
+    rng = np.random.default_rng(300 + S)
+    start, goal = np.array([-1.5, -1.5, 1.5]), np.array([1.5, 1.5, 0.4])
+    probs = []
+    for t in range(2):
+        scene = random_scene(n_boxes, 70 + t, (0.1, 0.6), start, goal)
+        p = build_path_problem(scene, start, goal, native.build_basis, n_vias=n_vias, n_samples_curve=S,
+                               collision_check_subsample=sub, moving_block_size=(0.9, 0.6, 0.6), start_yaw_deg=0.0,
+                               goal_yaw_deg=90.0, combined_4d=True, n_yaw_vias=n_vias,
+                               goal_approach_normals=np.array([[0.0, 0.0, 1.0]]), w_via_dev=0.3, w_yaw_dev=0.01)
+        probs.append(H.with_rotated_statics(p, seed=t) if rotated else p)
+    X = np.vstack([p.x0 + p.sigma0 * rng.normal(size=(37, p.dim)) for p in probs])
+    ref = oracle_lib.evaluate(probs, X, cands_per_task=37)
+    outs = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("MP_WIDE", mode)
+        ctx = native.Context(0)
+        ctx.set_problem(probs)
+        ctx.set_cands_per_task(37)
+        full = ctx.eval(X, want_grad=True, want_dist=True)
+        _compare(full, ref, np.float64)
+        nt = ctx.eval(X, want_grad=True, want_terms=False, want_dist=True)
+        co = ctx.eval(X, want_grad=False, want_terms=False, want_dist=True)
+        for o in (nt, co):
+            np.testing.assert_array_equal(o["dist"], ref["dist"])
+            np.testing.assert_array_equal(o["flags"], ref["flags"])
+            np.testing.assert_array_equal(o["min_clear"], ref["min_clear"])
+            assert H.rel_err(o["cost"], ref["cost"]).max() < 1e-9
+        assert _grad_err(nt["grad"], ref["grad"]) < 1e-9
+        outs[mode] = {"full": full, "nt": nt, "co": co}
+        ctx.close()
+    for k in ("full", "nt", "co"):
+        a, b = outs["1"][k], outs["0"][k]
+        for key in ("dist", "min_clear", "flags"):
+            np.testing.assert_array_equal(a[key], b[key], err_msg=f"{k}.{key}")
+        assert H.rel_err(a["cost"], b["cost"]).max() < 1e-12
+        if a["grad"] is not None:
+            assert _grad_err(a["grad"], b["grad"]) < 1e-11
