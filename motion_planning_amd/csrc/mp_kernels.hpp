@@ -360,6 +360,7 @@ __device__ __forceinline__ void clearance_chunk(const AT &a, const BoxRec<T> *bo
     // is skipped when no lane of the wave can be closer to its AABB than its current minimum.
     for (int g = 0; g < ngroups; ++g) {
         const BoxRec32 grp = load_box32_uniform(groups, 2 * g);
+        MP_STAT_ADD(7, 1);
         const int gfirst = __float_as_int(grp.pad0), gcnt = __float_as_int(grp.pad1);
         if (ngroups > 1) {
             const float lbg = aabb_lb2(mlox, mloy, mloz, mhix, mhiy, mhiz, grp);

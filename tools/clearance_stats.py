@@ -23,7 +23,7 @@ lib.mp_debug_stats(st)
 ctx.eval(X, want_grad=True)
 lib.mp_debug_stats(st)
 chunks, groups, boxes, pairs, drains = (st[i] for i in range(5))
-print(f"B={B} S={S} N={N}: chunks={chunks} per chunk: groups visited {groups / chunks:.1f}, boxes bound-tested {boxes / chunks:.1f}, "
+print(f"B={B} S={S} N={N}: chunks={chunks} per chunk: groups tested {st[7] / chunks:.1f}, groups visited {groups / chunks:.1f}, boxes bound-tested {boxes / chunks:.1f}, "
       f"pairs evaluated {pairs / chunks:.1f} in {drains / chunks:.2f} drains ({pairs / max(drains, 1):.1f} per drain); "
       f"of the pairs {100.0 * st[5] / max(pairs, 1):.1f} % xy-separated (need the rectangle distance), {100.0 * st[6] / max(pairs, 1):.1f} % overlapping")
 ctx.close()
