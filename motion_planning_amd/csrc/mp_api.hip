@@ -608,9 +608,16 @@ int launch_eval(mp_ctx *ctx, long long n, const void *X, const int32_t *task_of,
     // task), or when a trajectory has more than one 64-sample chunk and the scene is not tiny.  Measured on
     // MI355X (tools/shape_bench.py): B=200 S=64 -9 %, B=2000 S=64 -13 %, B=50 S=256 -32 %, B=2000 S=256 -75 %;
     // B=13 S=101 and B=50 S=64 are faster fused.
+    const int nw = std::min(4, std::max(3, (c.n_samples + 63) / 64));
+    const bool wide_ok = sizeof(T) == 8 && c.model == MP_MODEL_BOX && grad != nullptr && terms == nullptr && ctx->has_rot < 2 &&
+                         c.n_samples > ctx->wide_min_s && 3 * c.n_free + c.n_yaw_free <= 64 && ctx->wide_mode != 0 &&
+                         per_wave + nw * 64 * sizeof(T) <= ctx->max_lds;
     if (c.model == MP_MODEL_BOX) {
         const size_t pre_bytes = (size_t)n * (size_t)c.n_safe * (sizeof(T) + sizeof(int));
         bool split = ctx->split_mode == 1 || (ctx->split_mode < 0 && (ctx->max_task_boxes >= 128 || (c.n_safe > 64 && ctx->max_task_boxes >= 32)));
+        // ... and whenever the wide instance can take the launch: on long trajectories split + wide beats the fused kernel even
+        // for a handful of boxes (B=13: S=192 0.367 -> 0.276 ms, S=256 0.565 -> 0.321, S=512 0.998 -> 0.362; B=5 S=256 0.469 -> 0.289)
+        if (ctx->split_mode < 0 && wide_ok && ctx->max_task_boxes >= 1) split = true;
         if (ext_scratch) split = true;   // mp_eval_noalloc: always the split kernels, tables in the caller-independent static array
         if (split && pre_bytes <= ((size_t)16 << 30)) {
             if (ext_scratch) {
@@ -643,9 +650,7 @@ int launch_eval(mp_ctx *ctx, long long n, const void *X, const int32_t *task_of,
     // S=160 0.586 -> 0.611, S=192 0.360 -> 0.320 (four waves: 0.340), S=256 0.587 -> 0.433, S=512 0.788 -> 0.437; two-wave
     // blocks at S=101 lose (0.371 -> 0.410), and cost-only launches lose 1-5 % (their slices are half the size).
     size_t lds_launch = lds_bytes;
-    const int nw = std::min(4, std::max(3, (c.n_samples + 63) / 64));
-    if (sizeof(T) == 8 && a.pre_d && grad != nullptr && terms == nullptr && ctx->has_rot < 2 && c.n_samples > ctx->wide_min_s &&
-        3 * c.n_free + c.n_yaw_free <= 64 && ctx->wide_mode != 0 && per_wave + nw * 64 * sizeof(T) <= ctx->max_lds) {
+    if (wide_ok && a.pre_d) {
         a.wide = nw;
         wpb = nw;
         lds_launch = per_wave + nw * 64 * sizeof(T);
