@@ -481,7 +481,7 @@ int launch_eval_p(mp_ctx *ctx, const mp::EvalArgs<T> &args, int wpb, int blocks,
     if constexpr (sizeof(T) == 8 && MODEL == 1 && !GRAD && ROT == 0 && !PRE) {
         if (args.five_waves) kern = mp::eval_kernel<T, MODEL, GRAD, ROT, PRE, 6>;
     }
-    if constexpr (sizeof(T) == 8 && MODEL == 1 && ROT < 2 && PRE && GRAD) {
+    if constexpr (MODEL == 1 && ROT < 2 && PRE && GRAD) {
         if (args.wide == 4) kern = mp::eval_kernel<T, MODEL, GRAD, ROT, PRE, 0, 4>;
         if (args.wide == 3) kern = mp::eval_kernel<T, MODEL, GRAD, ROT, PRE, 0, 3>;
     }
@@ -609,7 +609,7 @@ int launch_eval(mp_ctx *ctx, long long n, const void *X, const int32_t *task_of,
     // MI355X (tools/shape_bench.py): B=200 S=64 -9 %, B=2000 S=64 -13 %, B=50 S=256 -32 %, B=2000 S=256 -75 %;
     // B=13 S=101 and B=50 S=64 are faster fused.
     const int nw = std::min(4, std::max(3, (c.n_samples + 63) / 64));
-    const bool wide_ok = sizeof(T) == 8 && c.model == MP_MODEL_BOX && grad != nullptr && terms == nullptr && ctx->has_rot < 2 &&
+    const bool wide_ok = c.model == MP_MODEL_BOX && grad != nullptr && terms == nullptr && ctx->has_rot < 2 &&
                          c.n_samples > ctx->wide_min_s && 3 * c.n_free + c.n_yaw_free <= 64 && ctx->wide_mode != 0 &&
                          per_wave + nw * 64 * sizeof(T) <= ctx->max_lds;
     if (c.model == MP_MODEL_BOX) {
@@ -644,11 +644,12 @@ int launch_eval(mp_ctx *ctx, long long n, const void *X, const int32_t *task_of,
             HIP_TRY(ctx, hipGetLastError());
         }
     }
-    // Wide instance (mp_kernels.hpp, NW = 3 / 4) for split-mode fp64 gradient launches without the term breakdown on long
+    // Wide instance (mp_kernels.hpp, NW = 3 / 4) for split-mode gradient launches without the term breakdown on long
     // trajectories: there the slice of a candidate leaves room for one or two waves per SIMD; one candidate per three- or
     // four-wave block keeps that many waves per slice busy.  Measured (B=50, cost+grad, standard -> wide): S=129 0.548 -> 0.583 ms,
     // S=160 0.586 -> 0.611, S=192 0.360 -> 0.320 (four waves: 0.340), S=256 0.587 -> 0.433, S=512 0.788 -> 0.437; two-wave
-    // blocks at S=101 lose (0.371 -> 0.410), and cost-only launches lose 1-5 % (their slices are half the size).
+    // blocks at S=101 lose (0.371 -> 0.410), and cost-only launches lose 1-5 % (their slices are half the size).  fp32 (slices
+    // half the size): S=192 +2 %, S=256 +8 %, S=512 +53 %.
     size_t lds_launch = lds_bytes;
     if (wide_ok && a.pre_d) {
         a.wide = nw;

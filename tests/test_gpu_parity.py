@@ -895,3 +895,37 @@ def test_wide_instance_matches_the_standard_one(shape, native, oracle_lib, monke
         assert H.rel_err(a["cost"], b["cost"]).max() < 1e-12
         if a["grad"] is not None:
             assert _grad_err(a["grad"], b["grad"]) < 1e-11
+
+
+@pytest.mark.parametrize("shape", [(50, 256, 1, 2), (13, 320, 2, 4)])
+def test_wide_instance_fp32(shape, native, oracle_lib, monkeypatch):
+    """The fp32 form of the wide instance: clearances and flags are the fp32 oracle's bits with and without it, cost and
+    gradient meet the fp32 bar (1e-4 / 2e-3) against the oracle and agree between the instances to rounding."""
+    from motion_planning_amd.problem import build_path_problem
+    from motion_planning_amd.synthetic import random_scene
+
+    n_boxes, S, sub, n_vias = shape
+    rng = np.random.default_rng(500 + S)
+    start, goal = np.array([-1.5, -1.5, 1.5]), np.array([1.5, 1.5, 0.4])
+    scene = random_scene(n_boxes, 90, (0.1, 0.6), start, goal)
+    prob = build_path_problem(scene, start, goal, native.build_basis, n_vias=n_vias, n_samples_curve=S,
+                              collision_check_subsample=sub, moving_block_size=(0.9, 0.6, 0.6), start_yaw_deg=0.0,
+                              goal_yaw_deg=90.0, combined_4d=True, n_yaw_vias=n_vias,
+                              goal_approach_normals=np.array([[0.0, 0.0, 1.0]]), w_via_dev=0.3, w_yaw_dev=0.01)
+    X = np.ascontiguousarray(prob.x0 + prob.sigma0 * rng.normal(size=(90, prob.dim)), dtype=np.float32)
+    ref = oracle_lib.evaluate(prob, X, dtype=np.float32)
+    outs = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("MP_WIDE", mode)
+        ctx = native.Context(0, np.float32)
+        ctx.set_problem(prob)
+        _compare(ctx.eval(X, want_grad=True, want_dist=True), ref, np.float32)
+        nt = ctx.eval(X, want_grad=True, want_terms=False, want_dist=True)
+        for key in ("dist", "min_clear", "flags"):
+            np.testing.assert_array_equal(nt[key], ref[key], err_msg=key)
+        assert H.rel_err(nt["cost"], ref["cost"]).max() < RTOL[np.float32]
+        assert _grad_err(nt["grad"].astype(float), ref["grad"].astype(float)) < 2e-3
+        outs[mode] = nt
+        ctx.close()
+    assert H.rel_err(outs["1"]["cost"], outs["0"]["cost"]).max() < 1e-5
+    assert _grad_err(outs["1"]["grad"].astype(float), outs["0"]["grad"].astype(float)) < 1e-4

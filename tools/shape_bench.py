@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Kernel time of one mp_eval launch for a list of (boxes, samples, candidates) shapes (fp64, cost+grad)."""
+"""Kernel time of one mp_eval launch for a list of (boxes, samples, candidates) shapes (cost+grad and cost only; fp64, or fp32
+with MP_SHAPE_DTYPE=f32)."""
 import sys
 from pathlib import Path
 
@@ -14,11 +15,12 @@ from motion_planning_amd.synthetic import synthetic_candidates, synthetic_proble
 shapes = [(50, 64, 65536), (50, 101, 32768), (13, 101, 65536), (200, 64, 32768), (2000, 64, 16384), (50, 256, 16384), (2000, 256, 16384)]
 if len(sys.argv) > 1:   # e.g. "50,64,65536;13,101,65536"
     shapes = [tuple(int(v) for v in t.split(",")) for t in sys.argv[1].split(";")]
+DT = np.float32 if __import__("os").environ.get("MP_SHAPE_DTYPE") == "f32" else np.float64
 for B, S, N in shapes:
     prob = synthetic_problem(_native.build_basis, B, S, seed=1 if B >= 1000 else 0, size_range=(0.05, 0.3) if B >= 1000 else (0.1, 0.6))
-    X = torch.from_numpy(synthetic_candidates(prob, N, seed=5)).cuda()
+    X = torch.from_numpy(synthetic_candidates(prob, N, seed=5).astype(DT)).cuda()
     for grad in (True, False):
-        db = DeviceBatch(prob, N, want_grad=grad)
+        db = DeviceBatch(prob, N, want_grad=grad, dtype=DT)
         db.evaluate(X)
         db.ctx.set_stream(torch.cuda.current_stream().cuda_stream)
         reps = int(__import__("os").environ.get("MP_SHAPE_REPS", "5"))   # 5: quick A/B; 100+: settled clocks (absolute figures)
