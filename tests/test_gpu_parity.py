@@ -929,3 +929,34 @@ def test_wide_instance_fp32(shape, native, oracle_lib, monkeypatch):
         ctx.close()
     assert H.rel_err(outs["1"]["cost"], outs["0"]["cost"]).max() < 1e-5
     assert _grad_err(outs["1"]["grad"].astype(float), outs["0"]["grad"].astype(float)) < 1e-4
+
+
+def test_wide_instance_contains_bad_task_indices(native):
+    """Out-of-range entries of a device-resident task_of on the wide instance (one candidate per block: every wave of the block
+    takes the same exit): NaN cost / gradient and no flag for those rows, every other row untouched."""
+    import torch
+
+    from motion_planning_amd.batch import DeviceBatch
+    from motion_planning_amd.problem import build_path_problem
+    from motion_planning_amd.synthetic import random_scene
+
+    start, goal = np.array([-1.5, -1.5, 1.5]), np.array([1.5, 1.5, 0.4])
+    probs = [build_path_problem(random_scene(20, 60 + t, (0.1, 0.6), start, goal), start, goal, native.build_basis, n_vias=2,
+                                n_samples_curve=256, moving_block_size=(0.9, 0.6, 0.6), start_yaw_deg=0.0, goal_yaw_deg=90.0,
+                                combined_4d=True, n_yaw_vias=2) for t in range(2)]
+    rng = np.random.default_rng(9)
+    X = torch.from_numpy(np.vstack([p.x0 + p.sigma0 * rng.normal(size=(24, p.dim)) for p in probs])).cuda()
+    db = DeviceBatch(probs, 48, want_grad=True)
+    good = torch.arange(48, device="cuda", dtype=torch.int32) // 24
+    ref = {k: v.clone() for k, v in db.evaluate(X, task_of=good).items()}
+    bad = good.clone()
+    bad[3], bad[30] = 2, -5
+    out = db.evaluate(X, task_of=bad)
+    torch.cuda.synchronize()
+    keep = torch.ones(48, dtype=torch.bool, device="cuda")
+    keep[3] = keep[30] = False
+    for key in ("cost", "min_clear", "flags", "grad"):
+        assert torch.equal(out[key][keep], ref[key][keep]), key
+    assert torch.isnan(out["cost"][~keep]).all() and torch.isnan(out["grad"][~keep]).all()
+    assert (out["flags"][~keep] == 0).all()
+    db.close()
