@@ -846,7 +846,7 @@ def test_five_wave_instance_is_bit_identical(shape, native, oracle_lib, monkeypa
 
 
 @pytest.mark.parametrize("shape", [(50, 256, 1, 2, False), (40, 129, 1, 3, False), (150, 200, 2, 6, False), (33, 300, 3, 2, True),
-                                   (60, 193, 1, 4, True), (45, 185, 1, 3, False), (5, 256, 1, 2, False), (13, 400, 4, 5, False)])
+                                   (60, 193, 1, 4, True), (45, 185, 1, 3, False), (5, 256, 1, 2, False), (13, 400, 4, 5, False), (13, 1024, 4, 2, False)])
 def test_wide_instance_matches_the_standard_one(shape, native, oracle_lib, monkeypatch):
     """Split-mode fp64 gradient launches without the term breakdown on trajectories of more than 176 samples go to the wide
     instance of eval_kernel (one candidate per three- or four-wave block, sums combined across the waves through LDS).
