@@ -197,6 +197,22 @@ class NativeEvaluator:
         out = self.ctx.eval(X, want_terms=want_terms, want_grad=want_grad, want_dist=want_dist)
         return {k: (None if v is None else np.asarray(v, dtype=float) if k != "flags" else v) for k, v in out.items()}
 
+    def cem_multi(self, x0, sigma0, seeds, population_size: int = 48, elite_frac: float = 0.2, max_iter: int = 60,
+                  tol: float = 1e-3, alpha: float = 0.7, min_sigma: float = 1e-3) -> List[Dict]:
+        """``len(seeds)`` CEM runs (ref :222-277) from the same start, resident on the device (``mp_cem_solve``: sampling,
+        evaluation, elite statistics and the stop rule of every run in lock-step, no host round trip per generation).  The
+        noise comes from the device generator keyed by ``seeds[0]`` and the run index — not NumPy's stream: the runs follow
+        the reference's update and stop rule, not its random numbers."""
+        R = len(seeds)
+        x0 = np.asarray(x0, dtype=float)
+        out = self.ctx.cem_solve(np.repeat(x0[None, :], R, axis=0), np.asarray(sigma0, dtype=float), population_size=population_size,
+                                 elite_frac=elite_frac, max_iter=max_iter, tol=tol, alpha=alpha, min_sigma=min_sigma, seed=seeds[0])
+        nit = np.asarray(out["nit"], dtype=int)
+        self.n_calls += int(nit.max())                       # one evaluation launch per generation for all runs
+        self.n_evals += int(nit.sum()) * int(population_size)
+        return [{"x": np.asarray(out["x"][k], dtype=float), "fun": float(out["fun"][k]), "nit": int(nit[k]), "success": True,
+                 "message": "CEM finished"} for k in range(R)]
+
     def clearance_profile(self, P: np.ndarray, yaw_deg: Optional[np.ndarray]) -> np.ndarray:
         """_path_distances over arbitrary samples (ref :148-186) with the problem's scene."""
         p = self.problem
@@ -397,13 +413,16 @@ def _refine_with_gradient(value_and_grad: Callable, x: np.ndarray, sigma0: np.nd
 
 
 def _solve_optimizer(objective_single, x0, sigma0, method: str, options: Optional[Dict] = None,
-                     objective_batch: Optional[Callable] = None, value_and_grad: Optional[Callable] = None) -> Dict:
+                     objective_batch: Optional[Callable] = None, value_and_grad: Optional[Callable] = None,
+                     cem_multi: Optional[Callable] = None) -> Dict:
     """Method dispatch and option merging of the reference (ref :280-388).
 
     ``objective_single(x)`` returns a tuple whose element 0 is the cost; ``objective_batch(X)``
     (optional) returns the cost vector of a population in one call.  One method beyond the reference's:
     ``"CEM-GRAD"`` — the hybrid with the Powell stage replaced by ``_refine_with_gradient`` (needs
-    ``value_and_grad``; options ``{"cem": {...}, "grad": {...}}``)."""
+    ``value_and_grad``; options ``{"cem": {...}, "grad": {...}, "device_cem": bool}``; ``cem_multi``: the evaluator's
+    device-resident lock-step CEM, used for stage 1 unless ``device_cem`` is False — then, and with an evaluator that has
+    none, the runs are NumPy-seeded host loops and run 0 is the reference's own seeded run)."""
     if objective_batch is None:
         def objective_batch(X):
             return np.array([objective_single(x)[0] for x in X], dtype=float)
@@ -424,6 +443,7 @@ def _solve_optimizer(objective_single, x0, sigma0, method: str, options: Optiona
         if value_and_grad is None:
             raise ValueError("method 'CEM-GRAD' needs an evaluator with gradients")
         cem, grad_opt = dict(_HYBRID_CEM_DEFAULTS), dict(_GRAD_DEFAULTS)
+        device_cem = bool(options.get("device_cem", True)) if options else True   # when the evaluator offers it (cem_multi)
         if options:
             if isinstance(options.get("cem"), dict):
                 cem.update(options["cem"])
@@ -440,7 +460,10 @@ def _solve_optimizer(objective_single, x0, sigma0, method: str, options: Optiona
         seed = cem.pop("seed")
         n_starts = max(1, int(grad_opt.pop("n_starts")))
         seeds = [seed if k == 0 else (None if seed is None else int(seed) + 1000 * k) for k in range(n_starts)]
-        stage1 = _cem_optimize_multi(objective_batch, x0, sigma0, seeds, **cem)
+        if device_cem and cem_multi is not None:
+            stage1 = cem_multi(x0, sigma0, seeds, **cem)     # every run on the device, one host call (NativeEvaluator.cem_multi)
+        else:
+            stage1 = _cem_optimize_multi(objective_batch, x0, sigma0, seeds, **cem)
         stage2 = _refine_with_gradient(value_and_grad, np.array([r["x"] for r in stage1]), sigma0, seed=seed, **grad_opt)
         lead = min(stage1, key=lambda r: r["fun"])
         nit1 = max(int(r["nit"]) for r in stage1)
@@ -597,7 +620,8 @@ def _solve_path(problem, evaluate, start, goal, start_yaw_deg, goal_yaw_deg, com
         return np.asarray(out["cost"], dtype=float), np.asarray(out["grad"], dtype=float)
 
     opt = _solve_optimizer(objective_single, x0=problem.x0, sigma0=problem.sigma0, method=method, options=options,
-                           objective_batch=objective_batch, value_and_grad=value_and_grad)
+                           objective_batch=objective_batch, value_and_grad=value_and_grad,
+                           cem_multi=getattr(evaluate, "cem_multi", None))
     x_opt = np.asarray(opt["x"], dtype=float)
     vias_opt = x_opt[:n_pos].reshape(problem.n_free, 3)
     if problem.n_yaw_free > 0:

@@ -544,11 +544,13 @@ def test_cem_grad_matches_cem_powell_on_the_shipped_scenarios():
                       start_yaw_deg=sc.start_yaw_deg, goal_yaw_deg=sc.goal_yaw_deg,
                       goal_approach_normals=np.asarray(sc.goal_normals, dtype=float), **BASE_CONFIG)
         _, _, ip = so.optimize_bspline_path(method="CEM-POWELL", options={"seed": 3}, evaluator_factory=counting("p"), **common)
-        _, vg, ig = so.optimize_bspline_path(method="CEM-GRAD", options={"seed": 3}, evaluator_factory=counting("g"), **common)
-        assert ig["fun"] <= 1.01 * ip["fun"], (name, ig["fun"], ip["fun"])
-        assert calls["g"].n_calls <= 60 + 1 + 40 + 3, (name, calls["g"].n_calls)       # + the post-solve evaluations
-        assert calls["g"].n_calls < calls["p"].n_calls
-        assert np.isfinite(vg).all() and ig["message"].startswith("Hybrid CEM+gradient")
+        for device_cem in (True, False):   # stage 1 resident on the device (the default) / NumPy-seeded lock-step runs on the host
+            _, vg, ig = so.optimize_bspline_path(method="CEM-GRAD", options={"seed": 3, "device_cem": device_cem},
+                                                 evaluator_factory=counting("g"), **common)
+            assert ig["fun"] <= 1.01 * ip["fun"], (name, device_cem, ig["fun"], ip["fun"])
+            assert calls["g"].n_calls <= 60 + 1 + 40 + 3, (name, calls["g"].n_calls)       # + the post-solve evaluations
+            assert calls["g"].n_calls < calls["p"].n_calls
+            assert np.isfinite(vg).all() and ig["message"].startswith("Hybrid CEM+gradient")
 
 
 def test_plain_c_caller(native, oracle_lib):

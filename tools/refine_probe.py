@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""CEM-GRAD against CEM-POWELL on the seven shipped scenarios (BASE_CONFIG), three seeds: cost, evaluator calls, wall time.
+"""CEM-GRAD (device-resident CEM stage, the default; and with the NumPy-seeded host stage) against CEM-POWELL on the seven shipped
+scenarios (BASE_CONFIG), three seeds: cost, evaluator calls, wall time.
 Writes profiles/r02_cem_grad_vs_powell.json (DESIGN.md 4b quotes it)."""
 import json
 import sys
@@ -22,7 +23,7 @@ for name, raw in scen.items():
                   goal_yaw_deg=sc.goal_yaw_deg, goal_approach_normals=np.asarray(sc.goal_normals, dtype=float), **BASE_CONFIG)
     for seed in (3, 11, 5):
         rec = {"scenario": name, "seed": seed}
-        for method in ("CEM-POWELL", "CEM-GRAD"):
+        for method in ("CEM-POWELL", "CEM-GRAD/host", "CEM-GRAD"):
             held = {}
 
             def factory(problem):
@@ -30,12 +31,15 @@ for name, raw in scen.items():
                 return held["ev"]
 
             t0 = time.perf_counter()
-            _, _, info = so.optimize_bspline_path(method=method, options={"seed": seed}, evaluator_factory=factory, **common)
+            opts = {"seed": seed, "device_cem": False} if method.endswith("/host") else {"seed": seed}
+            _, _, info = so.optimize_bspline_path(method=method.split("/")[0], options=opts, evaluator_factory=factory, **common)
             rec[method] = {"fun": info["fun"], "calls": held["ev"].n_calls, "evals": held["ev"].n_evals, "wall_ms": 1e3 * (time.perf_counter() - t0),
                            "min_clearance": info["min_clearance"]}
         rec["ratio"] = rec["CEM-GRAD"]["fun"] / rec["CEM-POWELL"]["fun"]
+        rec["ratio_host"] = rec["CEM-GRAD/host"]["fun"] / rec["CEM-POWELL"]["fun"]
         rows.append(rec)
         print(f"{name:30s} seed {seed:2d}: CEM-POWELL {rec['CEM-POWELL']['fun']:12.4f} ({rec['CEM-POWELL']['calls']:4d} calls, {rec['CEM-POWELL']['wall_ms']:6.1f} ms)  "
-              f"CEM-GRAD {rec['CEM-GRAD']['fun']:12.4f} ({rec['CEM-GRAD']['calls']:4d} calls, {rec['CEM-GRAD']['wall_ms']:6.1f} ms)  {rec['ratio'] - 1:+.2%}", flush=True)
+              f"CEM-GRAD {rec['CEM-GRAD']['fun']:12.4f} ({rec['CEM-GRAD']['calls']:4d} calls, {rec['CEM-GRAD']['wall_ms']:6.1f} ms)  {rec['ratio'] - 1:+.2%}  "
+              f"host CEM stage {rec['CEM-GRAD/host']['fun']:12.4f} ({rec['CEM-GRAD/host']['calls']:4d} calls, {rec['CEM-GRAD/host']['wall_ms']:6.1f} ms)  {rec['ratio_host'] - 1:+.2%}", flush=True)
 out = ROOT / "gpurun_out" if (ROOT / "gpurun_out").is_dir() else ROOT / "profiles"   # on the GPU box only gpurun_out/ travels back
 (out / "r02_cem_grad_vs_powell.json").write_text(json.dumps(rows, indent=1))
