@@ -87,7 +87,7 @@ def build_basis(n_ctrl: int, degree: int, n_samples: int) -> np.ndarray:
     return M
 
 
-_SMALL_CALL = 512   # rows up to which Context.eval reuses its own output buffers (and their ctypes pointers)
+_SMALL_CALL = 2048   # rows up to which Context.eval reuses its own output buffers (and their ctypes pointers)
 
 
 def _p(a: Optional[np.ndarray]):
