@@ -1,6 +1,8 @@
 """Randomised parity: planner configurations drawn at random (sample counts that are not multiples of the wave, up to
 14 vias, separate yaw spline, subsampled collision checks, every weight on or off, rotated and tilted static boxes, empty-ish and
 cluttered scenes), HIP path through the C ABI against the CPU oracle.  Same bar as tests/test_gpu_parity.py."""
+import os
+
 import numpy as np
 import pytest
 
@@ -54,7 +56,7 @@ def _random_path_problem(rng, basis_fn):
     return prob
 
 
-@pytest.mark.parametrize("seed", range(36))
+@pytest.mark.parametrize("seed", range(int(os.environ.get("MP_FUZZ_SEEDS", "36"))))   # MP_FUZZ_SEEDS=500: a longer one-off run
 def test_random_configuration_matches_oracle(seed, oracle_lib):
     from motion_planning_amd import _native as native
 
