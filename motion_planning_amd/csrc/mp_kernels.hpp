@@ -419,6 +419,9 @@ template <typename T, bool GRAD, int ROT = 0, int WV = 0, int NW = 1> constexpr 
 //     the deciding boxes as 16-bit values; the closed-form terms read the free waypoints from x itself;
 //   * during the exact passes the 32-bit deciding-box words (they need 32-bit LDS atomics) live in the low half of the
 //     records' kD slot, which is free until the clearance is written there at the end of the chunk.
+// NW = 3 | 4: the wide instance (split-mode gradient launches without term breakdown on trajectories of more than 176
+// samples): one candidate per block of NW waves, launched with 64 * NW threads per block and the standard slice + NW * 64
+// values (RED) of dynamic LDS; everything else — phases, layout, arithmetic per sample — is the NW = 1 code.
 template <typename T, int MODEL, bool GRAD, int ROT, bool PRE, int WV = 0, int NW = 1>
 __global__ void __launch_bounds__(256, (eval_min_waves<T, GRAD, ROT, WV, NW>())) eval_kernel(const EvalArgs<T> a_by_value)
 {
