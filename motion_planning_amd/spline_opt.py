@@ -361,19 +361,28 @@ def _refine_with_gradient(value_and_grad: Callable, x: np.ndarray, sigma0: np.nd
     Hinv = np.zeros((R, D, D))          # inverse Hessian estimate in scaled coordinates z = x / sigma0; zero until the first update
     rows = np.arange(R)
     eye = np.eye(D)
+    Q, G = qa.size, ga.size
+    K = A + Q + probes.shape[0] + G
+    trials = np.empty((R, K, D))
     nit, stalled, best_so_far = 0, 0, float(np.min(cost))
     for _ in range(int(iters)):
         nit += 1
         gz = grad * scale[None, :]
         unit = gz / np.maximum(np.linalg.norm(gz, axis=1, keepdims=True), 1e-30)
         dz = -np.einsum("rij,rj->ri", Hinv, gz)
-        trials = np.concatenate([
-            X[:, None, :] - (step[:, None, None] * al[None, :, None]) * (scale[None, :] * unit)[:, None, :],
-            X[:, None, :] + qa[None, :, None] * (dz * scale[None, :])[:, None, :],
-            X[:, None, :] + probes[None, :, :],
-            X[:, None, :] + ga[None, :, None] * last[:, None, :],
-        ], axis=1)
-        K = trials.shape[1]
+        # the fan, written into one buffer (same expressions as X - (step al) (scale unit), X + qa (dz scale), X + probes,
+        # X + ga last; no concatenation, no temporaries of the fan's size)
+        Xb = X[:, None, :]
+        part = trials[:, :A]
+        np.multiply(step[:, None, None] * al[None, :, None], (scale[None, :] * unit)[:, None, :], out=part)
+        np.subtract(Xb, part, out=part)
+        part = trials[:, A:A + Q]
+        np.multiply(qa[None, :, None], (dz * scale[None, :])[:, None, :], out=part)
+        np.add(Xb, part, out=part)
+        np.add(Xb, probes[None, :, :], out=trials[:, A + Q:K - G])
+        part = trials[:, K - G:]
+        np.multiply(ga[None, :, None], last[:, None, :], out=part)
+        np.add(Xb, part, out=part)
         c2, g2 = value_and_grad(trials.reshape(R * K, D))
         n_eval += R * K
         c2 = np.asarray(c2, dtype=float).reshape(R, K)
