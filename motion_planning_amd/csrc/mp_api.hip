@@ -649,7 +649,7 @@ int launch_eval(mp_ctx *ctx, long long n, const void *X, const int32_t *task_of,
     // four-wave block keeps that many waves per slice busy.  Measured (B=50, cost+grad, standard -> wide): S=129 0.548 -> 0.583 ms,
     // S=160 0.586 -> 0.611, S=192 0.360 -> 0.320 (four waves: 0.340), S=256 0.587 -> 0.433, S=512 0.788 -> 0.437; two-wave
     // blocks at S=101 lose (0.371 -> 0.410), and cost-only launches lose 1-5 % (their slices are half the size).  fp32 (slices
-    // half the size): S=192 +2 %, S=256 +8 %, S=512 +53 %.
+    // half the size, 7-wave register budget): S=192 +10 %, S=256 +16 %, S=512 +54 %.
     size_t lds_launch = lds_bytes;
     if (wide_ok && a.pre_d) {
         a.wide = nw;

@@ -17,7 +17,8 @@ namespace mp {
 #define MP_CLR_WAVES 6   // waves per SIMD clearance_kernel is register-budgeted for (measured: 4 0.934, 5 0.847, 6 0.792, 7 0.794, 8 0.815 ms)
 #endif
 #ifndef MP_WIDE_WAVES
-#define MP_WIDE_WAVES 4   // waves per SIMD the wide split-mode instance (eval_kernel, NW = 4) is register-budgeted for
+#define MP_WIDE_WAVES 5   // waves per SIMD the wide split-mode instance (eval_kernel, NW = 3 | 4) is register-budgeted for (96 VGPRs:
+                          // S=232, where five blocks fit the LDS, +5 % against the 4-wave budget; S=256, four blocks, unchanged)
 #endif
 #ifndef MP_COST64_WAVES
 #define MP_COST64_WAVES 5   // waves per SIMD the fp64 cost-only kernels are register-budgeted for (<= 96 VGPRs)
@@ -407,7 +408,7 @@ __device__ __forceinline__ void clearance_chunk(const AT &a, const BoxRec<T> *bo
 template <typename T, bool GRAD, int ROT = 0, int WV = 0, int NW = 1> constexpr int eval_min_waves()
 {
     if (WV > 0) return WV;
-    if (NW > 1) return MP_WIDE_WAVES;
+    if (NW > 1) return sizeof(T) == 4 ? MP_F32_WAVES : MP_WIDE_WAVES;
     return ROT == 2 ? 2   // the tilt routine is a real call: its registers count too
                     : (sizeof(T) == 4 ? MP_F32_WAVES : (GRAD ? MP_GRAD64_WAVES : MP_COST64_WAVES));
 }
