@@ -309,7 +309,10 @@ template <typename T> int upload_problem(mp_ctx *ctx, const mp_task *tasks)
     // Bound-pass tables: per distinct box range, the boxes sorted along a Morton curve (fp32 records,
     // pad0 = index relative to the range) and the AABBs of groups of kGroup consecutive boxes.
     {
-        constexpr int kGroup = 16, kGroupMin = 128;
+#ifndef MP_GROUP
+#define MP_GROUP 16
+#endif
+        constexpr int kGroup = MP_GROUP, kGroupMin = 128;
         std::vector<mp::BoxRec32> sb, gr;
         std::vector<mp::BoxPair32> sp;   // the sorted boxes two per record, group by group
         std::vector<std::array<int, 7>> done;  // begin, count, sbox_begin, group_begin, group_count, n_wide, spair_begin

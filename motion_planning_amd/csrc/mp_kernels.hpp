@@ -185,7 +185,10 @@ __host__ __device__ inline int lds_bytes_per_wave(int S, int e, bool grad, int w
 __host__ __device__ inline int lds_bytes_per_wave_five(int S) { return (15 * 8 * S + 256 + 15) & ~15; }
 // slice of the compact cost-only instance (WV = 6): records (7 fields) + keys + 256 bytes (W / 16-bit queue)
 __host__ __device__ inline int lds_bytes_per_wave_compact_cost(int S) { return (7 * 8 * S + 8 * S + 256 + 15) & ~15; }
-constexpr int kSeedStride = 8;   // the bound of a grouped scene is seeded from the representative of every 8th group
+#ifndef MP_SEED_STRIDE
+#define MP_SEED_STRIDE 8
+#endif
+constexpr int kSeedStride = MP_SEED_STRIDE;   // the bound of a grouped scene is seeded from the representative of every 8th group
 constexpr int kChunkRec = 7;   // record of clearance_kernel: P0 P1 P2 YW CC SS + 1 (odd)
 
 // ---- culled clearance of one chunk of <= 64 collision samples (one per lane) against a task's boxes ----
