@@ -612,9 +612,10 @@ int launch_eval(mp_ctx *ctx, long long n, const void *X, const int32_t *task_of,
     // MI355X (tools/shape_bench.py): B=200 S=64 -9 %, B=2000 S=64 -13 %, B=50 S=256 -32 %, B=2000 S=256 -75 %;
     // B=13 S=101 and B=50 S=64 are faster fused.
     const int nw = std::min(4, std::max(3, (c.n_samples + 63) / 64));
+    const int D_out = 3 * c.n_free + c.n_yaw_free;
+    const size_t wide_bytes = (size_t)mp::wide_block_bytes(c.n_samples, (int)sizeof(T), nw, D_out, a.w_elems);
     const bool wide_ok = c.model == MP_MODEL_BOX && grad != nullptr && terms == nullptr && ctx->has_rot < 2 &&
-                         c.n_samples > ctx->wide_min_s && 3 * c.n_free + c.n_yaw_free <= 64 && ctx->wide_mode != 0 &&
-                         per_wave + nw * 64 * sizeof(T) <= ctx->max_lds;
+                         c.n_samples > ctx->wide_min_s && ctx->wide_mode != 0 && wide_bytes <= ctx->max_lds;
     if (c.model == MP_MODEL_BOX) {
         const size_t pre_bytes = (size_t)n * (size_t)c.n_safe * (sizeof(T) + sizeof(int));
         bool split = ctx->split_mode == 1 || (ctx->split_mode < 0 && (ctx->max_task_boxes >= 128 || (c.n_safe > 64 && ctx->max_task_boxes >= 32)));
@@ -655,9 +656,13 @@ int launch_eval(mp_ctx *ctx, long long n, const void *X, const int32_t *task_of,
     // half the size, 7-wave register budget): S=192 +10 %, S=256 +16 %, S=512 +54 %.
     size_t lds_launch = lds_bytes;
     if (wide_ok && a.pre_d) {
+        // its block: records | deciding boxes | RED, no waypoint table in front and no work queue (mp_kernels.hpp, wide_block_bytes):
+        // 32,000 B at S = 256 with up to 8 outputs, so that five blocks fit the CU's 128 LDS granules of 1,280 B
         a.wide = nw;
+        a.wide_rs = mp::wide_red_stride(D_out);
+        a.lds_per_wave = mp::wide_red_offset(c.n_samples, (int)sizeof(T));
         wpb = nw;
-        lds_launch = per_wave + nw * 64 * sizeof(T);
+        lds_launch = wide_bytes;
         blocks = (int)std::min<long long>(n, (long long)ctx->num_cu * 16);
     }
     const bool g = grad != nullptr;

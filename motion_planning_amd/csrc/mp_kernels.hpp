@@ -70,6 +70,7 @@ template <typename T> struct EvalArgs {
     int w_elems;       // elements of the waypoint table W in front of the records
     int five_waves;    // 1: the launch uses the five-waves-per-SIMD instance and its compact LDS slice (see eval_kernel, WV)
     int wide;          // > 1: the launch uses the wide instance (one candidate per block of `wide` waves; see eval_kernel, NW)
+    int wide_rs;       // wide instance: values between the waves' shares in RED (a multiple of 8, >= the number of outputs D)
     int n_tasks;
     T w[kNTerms];
     T req, pref, appr_tgt, goal_tgt, radius, ax, ay, az;
@@ -188,6 +189,15 @@ __host__ __device__ inline int lds_bytes_per_wave_compact_cost(int S) { return (
 #ifndef MP_SEED_STRIDE
 #define MP_SEED_STRIDE 8
 #endif
+// block of the wide instance (eval_kernel, NW > 1): records | deciding boxes | RED (the waves' shares of the sums; also the
+// waypoint table during the spline pass); returns the offset of RED, `total` the bytes of dynamic LDS of the block
+__host__ __device__ inline int wide_red_offset(int S, int e) { return (rec_fields(true) * S * e + 4 * S + 15) & ~15; }
+__host__ __device__ inline int wide_red_stride(int D) { return ((D > 2 ? D : 2) + 7) & ~7; }
+__host__ __device__ inline int wide_block_bytes(int S, int e, int nw, int D, int w_elems)
+{
+    const int red = nw * wide_red_stride(D) > w_elems ? nw * wide_red_stride(D) : w_elems;
+    return wide_red_offset(S, e) + ((red * e + 15) & ~15);
+}
 constexpr int kSeedStride = MP_SEED_STRIDE;   // the bound of a grouped scene is seeded from the representative of every 8th group
 constexpr int kChunkRec = 7;   // record of clearance_kernel: P0 P1 P2 YW CC SS + 1 (odd)
 
@@ -484,23 +494,26 @@ __global__ void __launch_bounds__(256, (eval_min_waves<T, GRAD, ROT, WV, NW>()))
     T *base = reinterpret_cast<T *>(smem_raw + (size_t)slice * a.lds_per_wave);
     T *RED = reinterpret_cast<T *>(smem_raw + a.lds_per_wave);
     (void)RED;
-    T *REC = COMPACT ? base : base + a.w_elems;
+    T *REC = (COMPACT || WIDE) ? base : base + a.w_elems;
 #define RF(s_, f_) REC[(s_) * NREC + (f_)]
     // ordered clearance keys: field kGD of the records (fp64 gradient launches: stride NREC keys) or an array behind them
     constexpr bool KEYREC = key_in_record(GRAD, (int)sizeof(T));
     constexpr int KS = KEYREC ? NREC : 1;
-    unsigned char *behind = smem_raw + (size_t)slice * a.lds_per_wave + ((((COMPACT ? 0 : a.w_elems) + NREC * S_layout) * sizeof(T) + 7) & ~(size_t)7);
+    unsigned char *behind = smem_raw + (size_t)slice * a.lds_per_wave + (((((COMPACT || WIDE) ? 0 : a.w_elems) + NREC * S_layout) * sizeof(T) + 7) & ~(size_t)7);
     unsigned long long *MINKEY = KEYREC ? reinterpret_cast<unsigned long long *>(REC + (GRAD ? (int)kGD : 0))
                                         : reinterpret_cast<unsigned long long *>(behind);
     // deciding boxes: an int array behind the records; five-wave instance: the low half of the records' kD slot during the
     // exact passes (stride 2 * NREC ints), then 16-bit values in the queue's memory (ARG16)
     constexpr int AS = FIVE ? 2 * NREC : 1;
-    int *ARG = FIVE ? reinterpret_cast<int *>(REC + (int)kD) : reinterpret_cast<int *>(behind + (KEYREC ? 0 : 8 * (size_t)S_layout));
+    int *ARG = FIVE ? reinterpret_cast<int *>(REC + (int)kD) : reinterpret_cast<int *>(behind + ((KEYREC || WIDE) ? 0 : 8 * (size_t)S_layout));   // (wide: split mode, no keys)
     // compact cost-only form: MINKEY[S] | QW behind the records
     unsigned int *QUEUE = FIVE ? reinterpret_cast<unsigned int *>(behind)
                                : reinterpret_cast<unsigned int *>(ARG + (GRAD ? S_layout : 0));
     short *ARG16 = reinterpret_cast<short *>(QUEUE);
-    T *W = COMPACT ? reinterpret_cast<T *>(QUEUE) : base;
+    // wide instance: W is read by the spline pass only (the closed-form terms read x itself) and shares RED's memory, which
+    // is written after the barriers that follow that pass
+    T *W = COMPACT ? reinterpret_cast<T *>(QUEUE) : (WIDE ? RED : base);
+    const int RS = WIDE ? a.wide_rs : 64;   // distance, in values, between the waves' shares of the M^T g outputs in RED
     (void)ARG16;
     MP_PHASE_DECL;
     for (long long cand = WIDE ? (long long)blockIdx.x : (long long)blockIdx.x * wpb + wib; cand < a.n;
@@ -788,13 +801,13 @@ __global__ void __launch_bounds__(256, (eval_min_waves<T, GRAD, ROT, WV, NW>()))
         if (mask & (1u << 10))
             for (int j = 0; j < nf; ++j)
                 for (int c3 = 0; c3 < 3; ++c3) {
-                    T e = (COMPACT ? a.X[cand * D + 3 * j + c3] : W[4 * (ff + j) + c3]) - tk.ctrl[ff + j][c3];
+                    T e = ((COMPACT || WIDE) ? a.X[cand * D + 3 * j + c3] : W[4 * (ff + j) + c3]) - tk.ctrl[ff + j][c3];
                     t_via += e * e;
                 }
         if (mask & (1u << 11))
             for (int j = 0; j < Cy; ++j) {
                 // (five-wave instance: W is gone; the fixed yaw controls contribute exact zeros, like the reference's full sum)
-                T e = (COMPACT ? ((j >= 1 && j <= nyf) ? a.X[cand * D + 3 * nf + (j - 1)] : tk.yaw_ctrl[j]) : W[4 * j + 3]) - tk.yaw_ctrl[j];
+                T e = ((COMPACT || WIDE) ? ((j >= 1 && j <= nyf) ? a.X[cand * D + 3 * nf + (j - 1)] : tk.yaw_ctrl[j]) : W[4 * j + 3]) - tk.yaw_ctrl[j];
                 t_ydev += e * e;
             }
         // goal approach alignment: v = P[S-1] - P[first] (telescoped sum of the tail diffs)
@@ -1041,7 +1054,7 @@ __global__ void __launch_bounds__(256, (eval_min_waves<T, GRAD, ROT, WV, NW>()))
                 acc += dpp_mov<0x4E, 0xf, true>(acc);   // quad_perm [2,3,0,1]
                 acc += dpp_mov<0x141, 0xf, true>(acc);  // row_half_mirror: the other quad of this group of 8
                 if constexpr (WIDE) {
-                    if (o < D && sg8 == 0) RED[wv * 64 + o] = acc;   // this wave's share of the samples
+                    if (o < D && sg8 == 0) RED[wv * RS + o] = acc;   // this wave's share of the samples
                 } else if (o < D && sg8 == 0) {
                     const bool is_pos = o < 3 * nf;
                     const int jj = is_pos ? o / 3 : o - 3 * nf;
@@ -1059,14 +1072,14 @@ __global__ void __launch_bounds__(256, (eval_min_waves<T, GRAD, ROT, WV, NW>()))
                 const int o = lane + 64 * wv;
                 if (o < D) {
                     T acc = RED[o];
-                    for (int v = 1; v < NW; ++v) acc += RED[v * 64 + o];
+                    for (int v = 1; v < NW; ++v) acc += RED[v * RS + o];
                     const bool is_pos = o < 3 * nf;
                     const int jj = is_pos ? o / 3 : o - 3 * nf;
                     const int comp = is_pos ? o - 3 * jj : 0;
                     if (is_pos) {
-                        if (mask & (1u << 10)) acc += w[10] * T(2) * (W[4 * (ff + jj) + comp] - tk.ctrl[ff + jj][comp]);
+                        if (mask & (1u << 10)) acc += w[10] * T(2) * (a.X[cand * D + o] - tk.ctrl[ff + jj][comp]);
                     } else {
-                        if (mask & (1u << 11)) acc += w[11] * T(2) * (W[4 * (1 + jj) + 3] - tk.yaw_ctrl[1 + jj]);
+                        if (mask & (1u << 11)) acc += w[11] * T(2) * (a.X[cand * D + o] - tk.yaw_ctrl[1 + jj]);
                     }
                     gout[o] = acc;
                 }
