@@ -604,7 +604,18 @@ int launch_eval(mp_ctx *ctx, long long n, const void *X, const int32_t *task_of,
     }
     const size_t lds_bytes = per_wave * wpb;
     long long need = (n + wpb - 1) / wpb;
-    int blocks = (int)std::min<long long>(need, (long long)ctx->num_cu * 16);
+#ifndef MP_WIDE_BLOCKS_PER_CU
+#define MP_WIDE_BLOCKS_PER_CU 128   // config-4 shard, wide eval_kernel: 16 / 128 / 512 -> 1.56 / 1.46 / 1.48 ms
+#endif
+#ifndef MP_CLR_BLOCKS_PER_CU
+#define MP_CLR_BLOCKS_PER_CU 128    // config-4 shard, clearance_kernel: 32 / 64 / 128 / 256 / 512 -> 8.56 / 8.39 / 8.32 / 8.42 / 8.58 ms
+#endif
+#ifndef MP_BLOCKS_PER_CU
+#define MP_BLOCKS_PER_CU 128   // grid cap of eval_kernel per CU (grid-stride beyond it).  Measured at config 3, 65,536 candidates:
+                               // 5 / 10 / 16 / 32 / 64 / 128 / 1024 per CU -> 0.397 / 0.373 / 0.361 / 0.352 / 0.352 / 0.350 / 0.351 ms;
+                               // 1,048,576 candidates: 16 / 32 / 64 / 128 / 1024 -> 5.65 / 5.43 / 5.33 / 5.27 / 5.40 ms
+#endif
+    int blocks = (int)std::min<long long>(need, (long long)ctx->num_cu * MP_BLOCKS_PER_CU);
     if (blocks < 1) return MP_OK;
     // Split mode: the clearance profile is computed by clearance_kernel first (full occupancy whatever S is, bound
     // seeded from group representatives) when the scene is large enough to have box groups (>= 128 boxes in a
@@ -635,7 +646,7 @@ int launch_eval(mp_ctx *ctx, long long n, const void *X, const int32_t *task_of,
                 a.pre_arg = (int *)ctx->s_pre_arg.p;
             }
             const long long units = n * ((c.n_safe + 63) / 64);
-            const int cblocks = (int)std::min<long long>((units + 3) / 4, (long long)ctx->num_cu * 32);
+            const int cblocks = (int)std::min<long long>((units + 3) / 4, (long long)ctx->num_cu * MP_CLR_BLOCKS_PER_CU);
             const size_t clds = (size_t)4 * mp::clearance_lds_bytes_per_wave((int)sizeof(T));
             if (ctx->has_rot == 2)
                 hipLaunchKernelGGL((mp::clearance_kernel<T, 2>), dim3(cblocks), dim3(256), clds, ctx->stream, a);
@@ -663,7 +674,7 @@ int launch_eval(mp_ctx *ctx, long long n, const void *X, const int32_t *task_of,
         a.lds_per_wave = mp::wide_red_offset(c.n_samples, (int)sizeof(T));
         wpb = nw;
         lds_launch = wide_bytes;
-        blocks = (int)std::min<long long>(n, (long long)ctx->num_cu * 16);
+        blocks = (int)std::min<long long>(n, (long long)ctx->num_cu * MP_WIDE_BLOCKS_PER_CU);
     }
     const bool g = grad != nullptr;
     if (c.model == MP_MODEL_BOX)
