@@ -607,6 +607,9 @@ int launch_eval(mp_ctx *ctx, long long n, const void *X, const int32_t *task_of,
 #ifndef MP_WIDE_BLOCKS_PER_CU
 #define MP_WIDE_BLOCKS_PER_CU 128   // config-4 shard, wide eval_kernel: 16 / 128 / 512 -> 1.56 / 1.46 / 1.48 ms
 #endif
+#ifndef MP_CLR_WPB
+#define MP_CLR_WPB 4   // waves per block of clearance_kernel (config-4 shard: 1 / 2 / 4 -> 8.65 / 8.30 / 8.34 ms)
+#endif
 #ifndef MP_CLR_BLOCKS_PER_CU
 #define MP_CLR_BLOCKS_PER_CU 128    // config-4 shard, clearance_kernel: 32 / 64 / 128 / 256 / 512 -> 8.56 / 8.39 / 8.32 / 8.42 / 8.58 ms
 #endif
@@ -646,16 +649,16 @@ int launch_eval(mp_ctx *ctx, long long n, const void *X, const int32_t *task_of,
                 a.pre_arg = (int *)ctx->s_pre_arg.p;
             }
             const long long units = n * ((c.n_safe + 63) / 64);
-            const int cblocks = (int)std::min<long long>((units + 3) / 4, (long long)ctx->num_cu * MP_CLR_BLOCKS_PER_CU);
-            const size_t clds = (size_t)4 * mp::clearance_lds_bytes_per_wave((int)sizeof(T));
+            const int cblocks = (int)std::min<long long>((units + MP_CLR_WPB - 1) / MP_CLR_WPB, (long long)ctx->num_cu * MP_CLR_BLOCKS_PER_CU);
+            const size_t clds = (size_t)MP_CLR_WPB * mp::clearance_lds_bytes_per_wave((int)sizeof(T));
             if (ctx->has_rot == 2)
-                hipLaunchKernelGGL((mp::clearance_kernel<T, 2>), dim3(cblocks), dim3(256), clds, ctx->stream, a);
+                hipLaunchKernelGGL((mp::clearance_kernel<T, 2>), dim3(cblocks), dim3(64 * MP_CLR_WPB), clds, ctx->stream, a);
             else if (ctx->has_rot)
-                hipLaunchKernelGGL((mp::clearance_kernel<T, 1>), dim3(cblocks), dim3(256), clds, ctx->stream, a);
+                hipLaunchKernelGGL((mp::clearance_kernel<T, 1>), dim3(cblocks), dim3(64 * MP_CLR_WPB), clds, ctx->stream, a);
             else if (grad != nullptr)
-                hipLaunchKernelGGL((mp::clearance_kernel<T, 0>), dim3(cblocks), dim3(256), clds, ctx->stream, a);
+                hipLaunchKernelGGL((mp::clearance_kernel<T, 0>), dim3(cblocks), dim3(64 * MP_CLR_WPB), clds, ctx->stream, a);
             else   // cost only (a CEM population on a large scene): no deciding boxes
-                hipLaunchKernelGGL((mp::clearance_kernel<T, 0, false>), dim3(cblocks), dim3(256), clds, ctx->stream, a);
+                hipLaunchKernelGGL((mp::clearance_kernel<T, 0, false>), dim3(cblocks), dim3(64 * MP_CLR_WPB), clds, ctx->stream, a);
             HIP_TRY(ctx, hipGetLastError());
         }
     }
