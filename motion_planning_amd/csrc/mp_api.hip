@@ -22,6 +22,12 @@
 // address that hipGetSymbolAddress returned in mp_create (g_scratch_ptr); kernels get that pointer as an argument.
 static __device__ __align__(256) unsigned char scratch[MP_NOALLOC_SCRATCH_BYTES];
 
+#ifndef MP_WPB_LOW_WAVES
+#define MP_WPB_LOW_WAVES 0    // experiment knob: up to this many resident waves per CU the bar below is MP_WPB_PCT_LOW
+#endif
+#ifndef MP_WPB_PCT_LOW
+#define MP_WPB_PCT_LOW 95
+#endif
 #ifndef MP_WPB_PCT
 #define MP_WPB_PCT 75   // a smaller block must put a third more waves on the CU to be preferred (measured: 85, 75, 60)
 #endif
@@ -599,8 +605,10 @@ int launch_eval(mp_ctx *ctx, long long n, const void *X, const int32_t *task_of,
             waves_of[w] = std::min<size_t>(std::min<size_t>(ctx->max_lds / (per_wave * w), 16) * w, vgpr_cap);
             best = std::max(best, waves_of[w]);
         }
+        // (at low occupancy every wave counts: up to MP_WPB_LOW_WAVES resident waves the bar is MP_WPB_PCT_LOW per cent)
+        const size_t pct = best <= MP_WPB_LOW_WAVES ? MP_WPB_PCT_LOW : MP_WPB_PCT;
         for (int w = 1; w <= 4; ++w)
-            if (waves_of[w] > 0 && waves_of[w] * 100 >= best * MP_WPB_PCT) wpb = w;
+            if (waves_of[w] > 0 && waves_of[w] * 100 >= best * pct) wpb = w;
     }
     const size_t lds_bytes = per_wave * wpb;
     long long need = (n + wpb - 1) / wpb;
