@@ -22,11 +22,8 @@
 // address that hipGetSymbolAddress returned in mp_create (g_scratch_ptr); kernels get that pointer as an argument.
 static __device__ __align__(256) unsigned char scratch[MP_NOALLOC_SCRATCH_BYTES];
 
-#ifndef MP_WPB_LOW_WAVES
-#define MP_WPB_LOW_WAVES 0    // experiment knob: up to this many resident waves per CU the bar below is MP_WPB_PCT_LOW
-#endif
-#ifndef MP_WPB_PCT_LOW
-#define MP_WPB_PCT_LOW 95
+#ifndef MP_WPB_TWO
+#define MP_WPB_TWO 1   // 0: A/B of the two-wave-block rule in launch_eval
 #endif
 #ifndef MP_WPB_PCT
 #define MP_WPB_PCT 75   // a smaller block must put a third more waves on the CU to be preferred (measured: 85, 75, 60)
@@ -602,13 +599,16 @@ int launch_eval(mp_ctx *ctx, long long n, const void *X, const int32_t *task_of,
         const size_t vgpr_cap = (size_t)4 * (grad != nullptr ? mp::eval_min_waves<T, true>() : mp::eval_min_waves<T, false>());
         for (int w = 1; w <= 4; ++w) {
             if (per_wave * w > ctx->max_lds) break;
-            waves_of[w] = std::min<size_t>(std::min<size_t>(ctx->max_lds / (per_wave * w), 16) * w, vgpr_cap);
+            // blocks that fit: LDS is handed out in granules of 1,280 bytes (a 54,144-byte block takes 43 of the CU's 128)
+            const size_t fit = (ctx->max_lds / 1280) / ((per_wave * w + 1279) / 1280);
+            waves_of[w] = std::min<size_t>(std::min<size_t>(fit, 16) * w, vgpr_cap);
             best = std::max(best, waves_of[w]);
         }
-        // (at low occupancy every wave counts: up to MP_WPB_LOW_WAVES resident waves the bar is MP_WPB_PCT_LOW per cent)
-        const size_t pct = best <= MP_WPB_LOW_WAVES ? MP_WPB_PCT_LOW : MP_WPB_PCT;
         for (int w = 1; w <= 4; ++w)
-            if (waves_of[w] > 0 && waves_of[w] * 100 >= best * pct) wpb = w;
+            if (waves_of[w] > 0 && waves_of[w] * 100 >= best * MP_WPB_PCT) wpb = w;
+        // At low occupancy (<= 12 resident waves) two-wave blocks are taken when they put a fifth more waves on the CU than
+        // four-wave blocks and more than three-wave blocks (S = 108 ... 121 with gradient: 10 waves against 8 or 9, +7 ... +10 %).
+        if (MP_WPB_TWO && wpb >= 3 && best <= 12 && waves_of[4] > 0 && waves_of[2] * 5 >= waves_of[4] * 6 && waves_of[2] > waves_of[3]) wpb = 2;
     }
     const size_t lds_bytes = per_wave * wpb;
     long long need = (n + wpb - 1) / wpb;
