@@ -10,6 +10,7 @@ collective; the per-candidate (cost, min clearance, flags) of each step are all-
 RCCL asynchronously straight from the kernel's output buffers (two output slots), overlapped with the next step.
 
   python bench.py --gpus 1 --steps 200 --warmup 20
+  python bench.py --gpus N --steps K --warmup W          # starts the N ranks itself (motion_planning_amd/launch.py)
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
          --master-port P bench.py --gpus N --steps K --warmup W
 """
@@ -182,6 +183,20 @@ def main():
     ap.add_argument("--dtype", default="f64", choices=["f64", "f32"])
     args = ap.parse_args()
 
+    # `python bench.py --gpus N` without a launcher: start the N ranks ourselves, as a fresh child process, BEFORE anything
+    # here touches the GPU (motion_planning_amd/launch.py), relay its JSON line and exit with its code.  Fewer than N
+    # visible devices is an error, never a quiet one-rank run that prints n_gpus: 1.
+    from motion_planning_amd import launch
+
+    one_device = os.environ.get("MP_BENCH_ONE_DEVICE") == "1"
+    if args.gpus > 1 and not launch.under_launcher():
+        sys.exit(launch.self_launch(str(Path(__file__).resolve()), sys.argv[1:], args.gpus, one_device=one_device))
+    if launch.under_launcher() and int(os.environ["WORLD_SIZE"]) != args.gpus:
+        if int(os.environ.get("RANK", "0")) == 0:
+            print(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={os.environ['WORLD_SIZE']} ranks; "
+                  f"give both the same number", file=sys.stderr)
+        sys.exit(2)
+
     import torch
     import torch.distributed as dist
 
@@ -194,12 +209,15 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     # rehearsal knobs (one-GPU box): MP_BENCH_ONE_DEVICE=1 puts every rank on cuda:0, MP_BENCH_BACKEND=gloo
     # swaps RCCL for gloo; the driver's runs use neither
-    if os.environ.get("MP_BENCH_ONE_DEVICE") == "1":
+    if one_device:
         local_rank = 0
     backend = os.environ.get("MP_BENCH_BACKEND", "nccl")
     # MP_BENCH_FORCE_DIST=1 under torchrun with ONE rank drives the whole collective path (RCCL communicator, async gathers,
     # barrier) on a one-GPU box
     distributed = world > 1 or os.environ.get("MP_BENCH_FORCE_DIST") == "1"
+    if not one_device and torch.cuda.device_count() <= local_rank:
+        print(f"bench.py: rank {rank} has no GPU (LOCAL_RANK={local_rank}, {torch.cuda.device_count()} visible)", file=sys.stderr)
+        sys.exit(2)
     if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
@@ -209,8 +227,6 @@ def main():
             dist.init_process_group(backend)
     else:
         torch.cuda.set_device(0)
-    if args.gpus != world and rank == 0 and world > 1:
-        print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
     np_dtype = np.float64 if args.dtype == "f64" else np.float32
     tdtype = torch.float64 if args.dtype == "f64" else torch.float32
 

@@ -191,7 +191,9 @@ __host__ __device__ inline int lds_bytes_per_wave_compact_cost(int S) { return (
 #endif
 // block of the wide instance (eval_kernel, NW > 1): records | deciding boxes | RED (the waves' shares of the sums; also the
 // waypoint table during the spline pass); returns the offset of RED, `total` the bytes of dynamic LDS of the block
-__host__ __device__ inline int wide_red_offset(int S, int e) { return (rec_fields(true) * S * e + 4 * S + 15) & ~15; }
+// (the deciding boxes start at the 8-byte aligned end of the records, exactly where eval_kernel puts `behind`: with fp32
+// records and an odd S that is 4 bytes further than the records' own end, and RED must start behind THAT array)
+__host__ __device__ inline int wide_red_offset(int S, int e) { return ((((rec_fields(true) * S * e + 7) & ~7) + 4 * S) + 15) & ~15; }
 __host__ __device__ inline int wide_red_stride(int D) { return ((D > 2 ? D : 2) + 7) & ~7; }
 __host__ __device__ inline int wide_block_bytes(int S, int e, int nw, int D, int w_elems)
 {

@@ -271,3 +271,27 @@ def test_config5_job_does_not_depend_on_the_partition(tmp_path, native):
     np.testing.assert_array_equal(np.asarray(one["solved"], dtype=np.float64), rows[:, 1])
     np.testing.assert_array_equal(np.asarray(one["nit"], dtype=np.float64).sum(axis=1), rows[:, 2])
     assert line["solved"] == int(one["solved"].sum())
+
+
+def test_plain_bench_command_starts_its_own_ranks():
+    """`python bench.py --gpus 2 ...` with no launcher in front (how the driver calls it, BENCH_r02.json.cmd): bench.py starts
+    the two ranks itself as a fresh child (motion_planning_amd/launch.py) and relays the JSON line.  On the one-GPU box the
+    ranks share cuda:0 and the collectives go over gloo; the line must say n_gpus = 2, the last gather must carry the bytes
+    the rank's own kernels wrote, and the aggregate counts both ranks' candidates."""
+    env = dict(os.environ)
+    env.update(MP_BENCH_ONE_DEVICE="1", MP_BENCH_BACKEND="gloo", MP_BENCH_SCENARIOS="16")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MP_SPLIT_CLEARANCE"):
+        env.pop(k, None)
+    cmd = [sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1", "--settle-s", "0.05"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=170, env=env, cwd=str(ROOT))
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["steps"] == 4 and line["warmup"] == 1
+    assert line["extras"]["gather_own_rows_match"] is True
+    assert line["value"] == pytest.approx(2 * 65536 * 4 / (line["ms_per_step"] * 4e-3), rel=1e-9)
+    assert "cpu_baseline" not in line            # rank 0 at N = 1 only
+    # asking for more GPUs than the box has is an error, not a one-rank line
+    env.pop("MP_BENCH_ONE_DEVICE")
+    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "64", "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, timeout=120, env=env, cwd=str(ROOT))
+    assert r.returncode == 2 and "--gpus 64" in r.stderr and not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]

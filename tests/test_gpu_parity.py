@@ -920,10 +920,13 @@ def test_wide_instance_matches_the_standard_one(shape, native, oracle_lib, monke
             assert _grad_err(a["grad"], b["grad"]) < 1e-11
 
 
-@pytest.mark.parametrize("shape", [(50, 256, 1, 2), (13, 320, 2, 4)])
+@pytest.mark.parametrize("shape", [(50, 256, 1, 2), (13, 320, 2, 4), (50, 201, 1, 2), (13, 255, 1, 3), (20, 333, 1, 2)])
 def test_wide_instance_fp32(shape, native, oracle_lib, monkeypatch):
     """The fp32 form of the wide instance: clearances and flags are the fp32 oracle's bits with and without it, cost and
-    gradient meet the fp32 bar (1e-4 / 2e-3) against the oracle and agree between the instances to rounding."""
+    gradient meet the fp32 bar (1e-4 / 2e-3) against the oracle and agree between the instances to rounding.
+    Odd sample counts with every sample collision-checked (S = 201, 255, 333): there the fp32 records end 4 bytes before the
+    8-byte aligned start of the deciding boxes, and the last deciding box (the goal sample touches the table: its
+    d cost / d d is not zero) must not share its word with the first value of RED (round-2 advisor finding)."""
     from motion_planning_amd.problem import build_path_problem
     from motion_planning_amd.synthetic import random_scene
 

@@ -59,6 +59,69 @@ def test_noalloc_entry_point_equals_mp_eval(shape):
         ctx.close()
 
 
+@pytest.mark.parametrize("shape", [(40, 64, False), (30, 201, True), (25, 255, False), (150, 101, True)],
+                         ids=["two_tasks_64", "rotated_wide_odd_201", "wide_odd_255", "rotated_grouped_101"])
+def test_noalloc_with_tasks_rotations_and_the_wide_instance(shape):
+    """Round-2 advisor finding: the header promises mp_eval's bits for every box-model launch, so cover what the first test
+    does not — a device-resident task_of over two tasks with an out-of-range entry (NaN row, no flag), yaw-rotated statics
+    (clearance_kernel<T, 1>), and S > 176 with an odd sample count (the wide instance reading the static array), fp64 and
+    fp32; two calls in a row, the second smaller."""
+    import torch
+
+    from motion_planning_amd import _native as native
+    from motion_planning_amd.problem import build_path_problem
+    from motion_planning_amd.synthetic import random_scene
+    from tests import helpers as H
+
+    n_boxes, S, rotated = shape
+    start, goal = np.array([-1.5, -1.5, 1.5]), np.array([1.5, 1.5, 0.4])
+    probs = []
+    for t in range(2):
+        p = build_path_problem(random_scene(n_boxes, 40 + t, (0.1, 0.6), start, goal), start, goal, native.build_basis, n_vias=2,
+                               n_samples_curve=S, moving_block_size=(0.9, 0.6, 0.6), start_yaw_deg=0.0, goal_yaw_deg=90.0,
+                               combined_4d=True, n_yaw_vias=2, goal_approach_normals=np.array([[0.0, 0.0, 1.0]]))
+        probs.append(H.with_rotated_statics(p, seed=t) if rotated else p)
+    vp = C.c_void_p
+    for dtype in (np.float64, np.float32):
+        tdt = torch.float64 if dtype is np.float64 else torch.float32
+        ctx = native.Context(0, dtype)
+        ctx.set_problem(probs)
+        D = probs[0].dim
+        for n, seed in ((600, 11), (170, 12)):
+            rng = np.random.default_rng(seed)
+            tof_h = rng.integers(0, 2, size=n).astype(np.int32)
+            tof_h[5], tof_h[n - 3] = 2, -1          # outside the problem: NaN results, no flag, neighbours untouched
+            Xh = np.stack([probs[max(0, min(1, int(t)))].x0 + probs[0].sigma0 * rng.normal(size=D) for t in tof_h]).astype(dtype)
+            X, tof = torch.from_numpy(Xh).cuda(), torch.from_numpy(tof_h).cuda()
+            ref = {"cost": torch.empty(n, dtype=tdt, device="cuda"), "grad": torch.empty(n, D, dtype=tdt, device="cuda"),
+                   "minc": torch.empty(n, dtype=tdt, device="cuda"), "flags": torch.empty(n, dtype=torch.uint8, device="cuda")}
+            got = {k: torch.full_like(v, 3) for k, v in ref.items()}
+            rc = ctx.lib.mp_eval(ctx._h, n, vp(X.data_ptr()), vp(tof.data_ptr()), vp(ref["cost"].data_ptr()), None,
+                                 vp(ref["grad"].data_ptr()), vp(ref["minc"].data_ptr()), vp(ref["flags"].data_ptr()), None,
+                                 abi.MP_MEM_DEVICE)
+            assert rc == 0, ctx.lib.mp_last_error(ctx._h)
+            rc = ctx.lib.mp_eval_noalloc(ctx._h, n, vp(X.data_ptr()), vp(tof.data_ptr()), vp(got["cost"].data_ptr()),
+                                         vp(got["grad"].data_ptr()), vp(got["minc"].data_ptr()), vp(got["flags"].data_ptr()))
+            assert rc == 0, ctx.lib.mp_last_error(ctx._h)
+            ctx.synchronize()
+            bad = torch.zeros(n, dtype=torch.bool, device="cuda")
+            bad[5] = bad[n - 3] = True
+            assert torch.isnan(got["cost"][bad]).all() and torch.isnan(got["grad"][bad]).all() and (got["flags"][bad] == 0).all()
+            assert torch.isfinite(got["cost"][~bad]).all()
+            # mp_eval may take the fused kernel where mp_eval_noalloc always splits: the clearance profile (hence min clearance
+            # and flags) is the same bits either way; cost and gradient are the same arithmetic unless only one of the two
+            # launches takes the wide instance (S > 176: sums added in a different order)
+            assert torch.equal(got["flags"], ref["flags"])
+            assert torch.equal(got["minc"][~bad], ref["minc"][~bad])
+            tol = 1e-12 if dtype is np.float64 else 1e-5
+            c_g, c_r = got["cost"][~bad].double(), ref["cost"][~bad].double()
+            assert float(((c_g - c_r).abs() / c_r.abs().clamp_min(1e-12)).max()) <= tol
+            g_g, g_r = got["grad"][~bad].double(), ref["grad"][~bad].double()
+            scale = g_r.abs().amax(dim=1, keepdim=True).clamp_min(1e-6)
+            assert float(((g_g - g_r).abs() / scale).max()) <= (1e-11 if dtype is np.float64 else 1e-4)
+        ctx.close()
+
+
 def test_noalloc_limits_and_errors():
     import torch
 

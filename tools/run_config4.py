@@ -4,6 +4,7 @@ candidates sharded by index over the ranks of the job (131,072 per GPU on 8 GPUs
 of the per-candidate (cost, min clearance, flags).
 
   python tools/run_config4.py                                   # one GPU's shard (rank 3 of 8) of the 8-GPU job
+  python tools/run_config4.py --gpus 8                          # the 8-GPU job (starts its ranks itself; or under torchrun:)
   python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 tools/run_config4.py
 
 Candidates are a function of their GLOBAL index (every rank draws the same stream and keeps rows [lo, hi) of it), so the
@@ -43,12 +44,20 @@ def main():
     ap.add_argument("--shard-index", type=int, default=3)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--dtype", default="f64", choices=["f64", "f32"])
+    ap.add_argument("--gpus", type=int, default=1, help="> 1 without torchrun: this script starts that many ranks itself")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"])
     ap.add_argument("--one-device", action="store_true", help="every rank uses cuda:0 (rehearsal on a one-GPU box)")
     ap.add_argument("--force-dist", action="store_true", help="run the collective path even with one rank")
     ap.add_argument("--check-stride", type=int, default=4099)
     ap.add_argument("--dump", default=None, help="rank 0 writes the gathered rows and the inputs to this .npz")
     args = ap.parse_args()
+    # --gpus N without a launcher: start the N ranks as a fresh child process before anything here touches the GPU
+    from motion_planning_amd import launch
+
+    if args.gpus > 1 and not launch.under_launcher():
+        sys.exit(launch.self_launch(str(Path(__file__).resolve()), sys.argv[1:], args.gpus, one_device=args.one_device))
+    if launch.under_launcher() and args.gpus > 1 and int(os.environ["WORLD_SIZE"]) != args.gpus:
+        sys.exit(f"--gpus {args.gpus} but the launcher started WORLD_SIZE={os.environ['WORLD_SIZE']} ranks")
     import torch
     import torch.distributed as dist
 

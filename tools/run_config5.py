@@ -3,6 +3,7 @@
 CEM solve to the reference's stopping rule, all instances in lock-step on the GPU(s).
 
   python tools/run_config5.py --scenarios 10000 --restarts 32
+  python tools/run_config5.py --gpus G ...                    # starts the G ranks itself; or under torchrun:
   python -m torch.distributed.run --nproc-per-node G --master-addr 127.0.0.1 tools/run_config5.py ...
 Scenarios are sharded by index in contiguous blocks (batch.shard_bounds); the only exchange is one all-gather of
 per-scenario (best cost, solved flag, generations).  Restart offsets and device noise streams are keyed by the GLOBAL
@@ -28,10 +29,18 @@ def main():
     ap.add_argument("--max-iter", type=int, default=90)
     ap.add_argument("--seed", type=int, default=2)
     ap.add_argument("--dtype", default="f64", choices=["f64", "f32"])
+    ap.add_argument("--gpus", type=int, default=1, help="> 1 without torchrun: this script starts that many ranks itself")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"])
     ap.add_argument("--one-device", action="store_true", help="every rank uses cuda:0 (rehearsal on a one-GPU box)")
     ap.add_argument("--dump", default=None, help="rank 0 writes the gathered per-scenario table to this .npy")
     args = ap.parse_args()
+    # --gpus N without a launcher: start the N ranks as a fresh child process before anything here touches the GPU
+    from motion_planning_amd import launch
+
+    if args.gpus > 1 and not launch.under_launcher():
+        sys.exit(launch.self_launch(str(Path(__file__).resolve()), sys.argv[1:], args.gpus, one_device=args.one_device))
+    if launch.under_launcher() and args.gpus > 1 and int(os.environ["WORLD_SIZE"]) != args.gpus:
+        sys.exit(f"--gpus {args.gpus} but the launcher started WORLD_SIZE={os.environ['WORLD_SIZE']} ranks")
     import torch
     import torch.distributed as dist
 
