@@ -78,9 +78,10 @@ def test_sweep_on_hip_equals_sweep_on_oracle(oracle_lib, monkeypatch):
     monkeypatch.setattr(sweep, "_clock", lambda: 0.0)
 
     table = {k: v for k, v in H.load_scenarios().items() if k.startswith("step_0")}
-    names = sorted(table)[:3]           # 2 train + 1 held out
+    names = sorted(table)               # all four generated scenarios: 3 train + 1 held out, as in the reference's main
+    assert len(names) == 4
     build = lambda n: scenario_from_resolved(table[n])
-    for method in ("CEM", "Powell"):
+    for method in ("CEM", "Powell", "CEM-POWELL"):
         hip = sweep.run_sweep(build, names, methods=(method,), trials=2, seed=7, log=None)
         orc = sweep.run_sweep(build, names, methods=(method,), trials=2, seed=7, log=None,
                               evaluator_factory=oracle_lib.OracleEvaluator)

@@ -371,6 +371,17 @@ def test_full_size_properties(native):
     ref = orc.evaluate(prob, Xh[idx])
     assert np.array_equal(ref["flags"], flags[idx]) and np.array_equal(ref["min_clear"], minc[idx])
     assert H.rel_err(cost[idx], ref["cost"]).max() < 1e-9
+    assert _grad_err(grad[idx], ref["grad"]) < 1e-9
+    # the launch every batch job makes (no term breakdown: the five-waves-per-SIMD instance at the full 16,384-block grid):
+    # same flags / clearances, cost and gradient against the oracle on the same strided sample
+    db5 = DeviceBatch(prob, n, want_grad=True, want_terms=False)
+    o5 = db5.evaluate(X)
+    torch.cuda.synchronize()
+    c5, g5, f5, m5 = (o5[k].cpu().numpy() for k in ("cost", "grad", "flags", "min_clear"))
+    assert np.array_equal(f5, flags) and np.array_equal(m5, minc)
+    assert H.rel_err(c5[idx], ref["cost"]).max() < 1e-9 and _grad_err(g5[idx], ref["grad"]) < 1e-9
+    assert H.rel_err(c5, cost).max() < 1e-12 and np.all(np.isfinite(g5))
+    db5.close()
     db.close()
 
 
@@ -405,12 +416,10 @@ def test_end_to_end_planner_on_gpu(rec):
     # vias (line searches on a flat minimum amplify the 1e-16 objective difference): bound = 10x measured
     assert info["nit"] == ref["nit"] and info["message"] == ref["message"]
     assert info["fun"] == pytest.approx(ref["fun"], rel=1e-9), achieved
-    if "powell" in rec["name"] or "hybrid" in rec["name"]:
-        np.testing.assert_allclose(vias, rv, rtol=0, atol=6.5e-9, err_msg=str(achieved))
-        assert info["min_clearance"] == pytest.approx(ref["min_clearance"], rel=1e-9, abs=1.5e-10), achieved
-    else:
-        np.testing.assert_allclose(vias, rv, rtol=1e-9, atol=1e-12, err_msg=str(achieved))
-        assert info["min_clearance"] == pytest.approx(ref["min_clearance"], rel=1e-9, abs=1e-12), achieved
+    # every solve is held to the bar itself, element by element (Powell / hybrid included: 5.8e-10 / 5.4e-10 relative in the
+    # vias, 4.4e-11 / 1.4e-10 in the min clearance as measured; the residual is explained in DESIGN.md 6)
+    np.testing.assert_allclose(vias, rv, rtol=1e-9, atol=1e-12, err_msg=str(achieved))
+    assert info["min_clearance"] == pytest.approx(ref["min_clearance"], rel=1e-9, abs=1e-12), achieved
     assert (info["min_clearance"] < 0) == (ref["min_clearance"] < 0)
 
 

@@ -152,3 +152,29 @@ def test_step_scenario_generator_reproduces_the_reference_data_file():
     np.testing.assert_allclose(via, (0.0, 1.0, 0.0), atol=1e-12)
     with pytest.raises(ValueError):
         goal_and_via_for_placement(blk, 0, "under")
+
+
+def test_placement_helper_equals_the_reference():
+    """tests/golden/g6_placement.json: 28 placements computed by the reference's own `goal_and_via_for_placement`
+    (geom/planning.py:6-95, run from its function body by tools/gen_golden.py with the reference's quat_to_rot): all five
+    directions, mixed case, identity / yaw-only / general quaternions, default and random keyword arguments."""
+    import json
+
+    import numpy as np
+    import pytest
+
+    from motion_planning_amd.planning import goal_and_via_for_placement
+    from tests import helpers as H
+
+    g6 = json.loads((H.GOLDEN / "g6_placement.json").read_text())
+    assert len(g6["cases"]) == 28 and {c["direction"].lower() for c in g6["cases"]} == {"front", "back", "left", "right", "top"}
+    for c in g6["cases"]:
+        s = Scene()
+        s.add_block(tuple(c["size"]), tuple(c["position"]), quat=tuple(c["quat"]), object_id="b")
+        kw = {k: (tuple(v) if isinstance(v, list) else v) for k, v in c["kwargs"].items()}
+        goal, via = goal_and_via_for_placement(s, "b", c["direction"], **kw)
+        np.testing.assert_allclose(goal, c["goal"], rtol=0, atol=2e-15)     # same products, summed in the reference's order
+        np.testing.assert_allclose(via, c["via"], rtol=0, atol=2e-15)
+    with pytest.raises(ValueError) as ei:
+        goal_and_via_for_placement(s, "b", "bottom")
+    assert str(ei.value) == g6["bad_direction_message"]

@@ -47,3 +47,29 @@ def test_small_sweep_end_to_end(oracle_lib):
         sweep.run_sweep(lambda n: None, [], log=None)
     with pytest.raises(ValueError, match="Unsupported method"):
         sweep.run_sweep(lambda n: None, names, methods=("Adam",), log=None)
+
+
+def test_draws_and_scores_equal_the_reference(golden_dir=H.GOLDEN):
+    """tests/golden/g6_sweep_draws.json: `_sample_strategy_config` and `_scenario_score` of the reference
+    (example/benchmark_planners.py:64-117), run from its own function bodies by tools/gen_golden.py, for the sweep's three
+    per-method seeds (7 / 10007 / 20007) x 12 trials drawn from ONE generator per method as `_hyperopt` does (:239-269),
+    plus other spellings of the method names.  Configurations, options (value AND type) and scores must be equal."""
+    import json
+
+    from motion_planning_amd.configs import BASE_CONFIG
+
+    g6 = json.loads((golden_dir / "g6_sweep_draws.json").read_text())
+    assert BASE_CONFIG == g6["base_config"]
+    for rec in g6["draws"]:
+        rng = np.random.default_rng(rec["seed"])
+        for t in rec["trials"]:
+            cfg, opts = sweep.sample_strategy_config(rec["method"], rng)
+            want = dict(g6["base_config"])
+            want.update(t["config_diff"])
+            assert cfg == want and len(cfg) == t["config_keys"]
+            assert opts == t["options"]
+            flat = lambda d: [(k, type(v)) for k, v in sorted(d.items()) if not isinstance(v, dict)] + \
+                             [x for k, v in sorted(d.items()) if isinstance(v, dict) for x in flat(v)]
+            assert flat(opts) == flat(t["options"])          # ints stay ints (JSON keeps the distinction)
+    for rec in g6["scores"]:
+        assert sweep.scenario_score(rec["info"], rec["runtime_s"]) == rec["score"]

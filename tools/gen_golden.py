@@ -327,6 +327,107 @@ def gen_g5(ref, scenarios):
     (OUT / "g5_solve.json").write_text(json.dumps(runs, indent=1))
 
 
+def _extract_functions(path, names, namespace):
+    """Compile the named top-level functions (and the named top-level assignments) of a reference source file into
+    `namespace` WITHOUT importing the module: example/benchmark_planners.py and geom/planning.py import geom -> fcl at
+    module level, but the bodies needed here use NumPy only.  Nothing of the source text is kept."""
+    import ast
+
+    tree = ast.parse(Path(path).read_text())
+    keep = []
+    for node in tree.body:
+        if isinstance(node, ast.FunctionDef) and node.name in names:
+            keep.append(node)
+        elif isinstance(node, (ast.Assign, ast.AnnAssign)):
+            targets = node.targets if isinstance(node, ast.Assign) else [node.target]
+            if any(isinstance(t, ast.Name) and t.id in names for t in targets):
+                keep.append(node)
+    found = {n.name if isinstance(n, ast.FunctionDef) else (n.targets[0].id if isinstance(n, ast.Assign) else n.target.id) for n in keep}
+    missing = set(names) - found
+    if missing:
+        raise RuntimeError(f"{path}: {sorted(missing)} not found")
+    exec(compile(ast.Module(body=keep, type_ignores=[]), str(path), "exec"), namespace)
+    return namespace
+
+
+def gen_g6():
+    """The two host helpers whose counterparts were only checked by eye: the sweep's random-search draws and
+    score (example/benchmark_planners.py:30-117) and the placement helper (geom/planning.py:6-95), run from the reference's
+    own function bodies."""
+    from typing import Any, Dict, Tuple
+
+    ns = {"np": np, "Dict": Dict, "Any": Any, "Tuple": Tuple}
+    _extract_functions(REF / "example" / "benchmark_planners.py", {"BASE_CONFIG", "_sample_strategy_config", "_scenario_score"}, ns)
+    draws = []
+    for method, seed in (("Powell", 7), ("CEM", 10007), ("CEM-POWELL", 20007), ("hybrid", 123), ("powell", 99), ("cem", 5)):
+        rng = np.random.default_rng(seed)
+        trials = []
+        for _ in range(12):     # one generator over the trials of a method, as in _hyperopt (benchmark_planners.py:239-269)
+            cfg, opts = ns["_sample_strategy_config"](method, rng)
+            # the config is BASE_CONFIG with the drawn keys replaced: only what differs is stored
+            trials.append({"config_diff": {k: v for k, v in cfg.items() if ns["BASE_CONFIG"].get(k) != v},
+                           "config_keys": len(cfg), "options": opts})
+        draws.append({"method": method, "seed": seed, "trials": trials})
+    scores = []
+    rs = np.random.default_rng(61)
+    for _ in range(24):
+        info = {"fun": float(rs.uniform(0.5, 400.0)), "min_clearance": float(rs.uniform(-0.2, 0.2)), "success": bool(rs.random() < 0.7)}
+        if rs.random() < 0.15:
+            del info["min_clearance"]
+        if rs.random() < 0.15:
+            del info["success"]
+        rt = float(rs.uniform(0.0, 30.0))
+        scores.append({"info": info, "runtime_s": rt, "score": ns["_scenario_score"](info, rt)})
+    (OUT / "g6_sweep_draws.json").write_text(json.dumps({"base_config": ns["BASE_CONFIG"], "draws": draws, "scores": scores}, indent=1))
+
+    uns = {"np": np}
+    _extract_functions(REF / "geom" / "utils.py", {"quat_to_rot"}, uns)
+    pns = {"np": np, "Tuple": Tuple, "Scene": object, "quat_to_rot": uns["quat_to_rot"]}
+    _extract_functions(REF / "geom" / "planning.py", {"goal_and_via_for_placement"}, pns)
+
+    class _Blk:
+        def __init__(self, size, position, quat):
+            self.size, self.position, self.quat = size, position, quat
+
+    class _Scene:
+        def __init__(self, blk):
+            self.blk = blk
+
+        def get_block(self, _id):
+            return self.blk
+
+    rp = np.random.default_rng(62)
+    cases = []
+    dirs = ["front", "back", "left", "right", "top", "Front", "TOP"]
+    for i in range(28):
+        size = [float(v) for v in rp.uniform(0.2, 1.2, 3)]
+        pos = [float(v) for v in rp.uniform(-1.5, 1.5, 3)]
+        if i % 3 == 0:
+            quat = [0.0, 0.0, 0.0, 1.0]
+        elif i % 3 == 1:
+            h = 0.5 * float(rp.uniform(-np.pi, np.pi))
+            quat = [0.0, 0.0, float(np.sin(h)), float(np.cos(h))]
+        else:
+            q = rp.normal(size=4)
+            quat = [float(v) for v in q / np.linalg.norm(q)]
+        kw = {"gap": float(rp.uniform(0.0, 0.05)), "lateral_offset": [float(v) for v in rp.uniform(-0.3, 0.3, 2)],
+              "interlock_x": float(rp.uniform(-0.2, 0.2)), "via_shift_along_normal": float(rp.uniform(0.0, 0.2)),
+              "via_offset_local": [float(v) for v in rp.uniform(-0.3, 0.3, 3)]}
+        if i < 5:
+            kw = {}        # the defaults
+        d = dirs[i % len(dirs)]
+        goal, via = pns["goal_and_via_for_placement"](_Scene(_Blk(size, pos, quat)), "b", d,
+                                                       **{k: (tuple(v) if isinstance(v, list) else v) for k, v in kw.items()})
+        cases.append({"size": size, "position": pos, "quat": quat, "direction": d, "kwargs": kw,
+                      "goal": [float(v) for v in goal], "via": [float(v) for v in via]})
+    err = None
+    try:
+        pns["goal_and_via_for_placement"](_Scene(_Blk([1, 1, 1], [0, 0, 0], [0, 0, 0, 1])), "b", "bottom")
+    except ValueError as exc:
+        err = str(exc)
+    (OUT / "g6_placement.json").write_text(json.dumps({"cases": cases, "bad_direction_message": err}, indent=1))
+
+
 def gen_payload():
     """The parsed content of the reference's example/generated_scenarios.yaml (a data file, the output of its
     generate_scenarios.py): pins motion_planning_amd.synthetic.generate_step_scenarios."""
@@ -339,6 +440,9 @@ def main():
     if "--payload-only" in sys.argv:
         gen_payload()
         return
+    if "--g6-only" in sys.argv:
+        gen_g6()
+        return
     ref = load_ref()
     rng = np.random.default_rng(20260220)
     scenarios = resolve_yaml_scenarios()
@@ -350,6 +454,7 @@ def main():
     gen_g3(ref, rng, scenarios)
     gen_g4(ref, rng)
     gen_g5(ref, scenarios)
+    gen_g6()
     gen_payload()
     (OUT / "META.json").write_text(json.dumps(meta, indent=1))
     print("wrote", sorted(p.name for p in OUT.iterdir()))
