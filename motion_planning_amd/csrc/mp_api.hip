@@ -308,6 +308,10 @@ template <typename T> int upload_problem(mp_ctx *ctx, const mp_task *tasks)
         dt[i].yaw_inc = tasks[i].yaw_increasing;
         dt[i].box_begin = tasks[i].box_begin;
         dt[i].box_count = tasks[i].box_count;
+        // initial value of every optimisation variable (free waypoint rows, then the free yaw controls)
+        for (int o = 0; o < 64; ++o) dt[i].xref[o] = T(0);
+        for (int o = 0; o < 3 * c.n_free && o < 64; ++o) dt[i].xref[o] = (T)tasks[i].ctrl[c.first_free + o / 3][o % 3];
+        for (int o = 0; o < c.n_yaw_free && 3 * c.n_free + o < 64; ++o) dt[i].xref[3 * c.n_free + o] = (T)tasks[i].yaw_ctrl[1 + o];
     }
     // Bound-pass tables: per distinct box range, the boxes sorted along a Morton curve (fp32 records,
     // pad0 = index relative to the range) and the AABBs of groups of kGroup consecutive boxes.
@@ -541,7 +545,7 @@ int launch_eval(mp_ctx *ctx, long long n, const void *X, const int32_t *task_of,
     a.w_elems = mp::w_elems_for(c.n_ctrl, c.n_yaw_ctrl);
     a.lds_per_wave = mp::lds_bytes_per_wave(c.n_samples, (int)sizeof(T), grad != nullptr, a.w_elems);
     a.n_tasks = ctx->n_tasks;
-    for (int i = 0; i < MP_NTERMS; ++i) a.w[i] = (T)c.weights[i];
+    for (int i = 0; i < MP_NTERMS; ++i) { a.w[i] = (T)c.weights[i]; a.w2[i] = a.w[i] * T(2); }
     a.req = (T)c.required_clearance; a.pref = (T)c.preferred_clearance; a.appr_tgt = (T)c.approach_target;
     a.goal_tgt = (T)c.goal_clearance_target; a.radius = (T)c.point_radius;
     a.ax = (T)c.half_extents[0]; a.ay = (T)c.half_extents[1]; a.az = (T)c.half_extents[2];

@@ -807,14 +807,19 @@ template <typename T> __device__ __forceinline__ T wave_sum(T v)
     return read_lane63(v);
 }
 template <typename T> __device__ __forceinline__ T lane_min(T a, T b) { return b < a ? b : a; }
+__device__ __forceinline__ int lane_min_fast(int a, int b) { return b < a ? b : a; }
+// floating-point operands are never NaN here (a running minimum only ever takes a value that compared smaller, and a CEM
+// cost has its NaNs replaced by +inf before the reduction): one v_min instead of a compare and two selects
+__device__ __forceinline__ float lane_min_fast(float a, float b) { return __builtin_fminf(a, b); }
+__device__ __forceinline__ double lane_min_fast(double a, double b) { return __builtin_fmin(a, b); }
 template <typename T> __device__ __forceinline__ T wave_min(T v)
 {
-    v = lane_min(v, dpp_mov<0xB1, 0xf, false>(v));
-    v = lane_min(v, dpp_mov<0x4E, 0xf, false>(v));
-    v = lane_min(v, dpp_mov<0x141, 0xf, false>(v));
-    v = lane_min(v, dpp_mov<0x140, 0xf, false>(v));
-    v = lane_min(v, dpp_mov<0x142, 0xa, false>(v));
-    v = lane_min(v, dpp_mov<0x143, 0xc, false>(v));
+    v = lane_min_fast(v, dpp_mov<0xB1, 0xf, false>(v));
+    v = lane_min_fast(v, dpp_mov<0x4E, 0xf, false>(v));
+    v = lane_min_fast(v, dpp_mov<0x141, 0xf, false>(v));
+    v = lane_min_fast(v, dpp_mov<0x140, 0xf, false>(v));
+    v = lane_min_fast(v, dpp_mov<0x142, 0xa, false>(v));
+    v = lane_min_fast(v, dpp_mov<0x143, 0xc, false>(v));
     return read_lane63(v);
 }
 

@@ -61,6 +61,7 @@ template <typename T> struct DevTask {
     int group_begin;   // first group of this task in the group table (records 2*group_begin ...)
     int group_count;   // groups of kGroupSize consecutive sorted boxes (1 group: no group test)
     int n_wide;        // 1: record 0 of the sorted table is a wide box handled before the sweep (clearance_chunk)
+    T xref[64];        // initial value of optimisation variable o (the via / yaw control it deviates from), o < D <= 56
 };
 
 template <typename T> struct EvalArgs {
@@ -73,6 +74,7 @@ template <typename T> struct EvalArgs {
     int wide_rs;       // wide instance: values between the waves' shares in RED (a multiple of 8, >= the number of outputs D)
     int n_tasks;
     T w[kNTerms];
+    T w2[kNTerms];     // 2 w[i] (exact): the factor of every d(e^2) in the reverse sweep
     T req, pref, appr_tgt, goal_tgt, radius, ax, ay, az;
     TrigTab<T> trig;        // constants of yaw_rot (mp_device.hpp)
     T du, inv_du, inv_h2;   // 1/(S-1), 1/du, 1/(2 du) in T arithmetic (host: the same correctly rounded divisions)
@@ -145,6 +147,38 @@ __device__ __forceinline__ void spline_sample(const T *__restrict__ m, const T *
     }
     yw = my[0] * W[3];
     for (int j = 1; j < Cy; ++j) yw = mp_fma(my[j], W[4 * j + 3], yw);
+}
+
+// The reference's default layout (n_vias = 2, combined_4d: four waypoints, the middle two free, two free yaw controls):
+// the waypoints never go through LDS.  Fixed rows come from the task record (wave-uniform: scalar operands), the free
+// ones are the candidate's x itself, read by every lane from the same 64 bytes.  Same fma chain, same bits.
+template <typename T> struct TaskEnds { T s0, s1, s2, g0, g1, g2, y0, y3; };   // first / last waypoint, first / last yaw control
+// read through the constant address space: the task table is read-only for the launch and the task is wave-uniform, so
+// the eight values arrive over the scalar data path and stay scalar operands of the fma chain
+template <typename T, typename TK> __device__ __forceinline__ TaskEnds<T> load_task_ends(const TK &tk)
+{
+    typedef const T __attribute__((address_space(4))) *CPtr;
+    CPtr c = (CPtr)(unsigned long long)(&tk.ctrl[0][0]);
+    CPtr y = (CPtr)(unsigned long long)(&tk.yaw_ctrl[0]);
+    TaskEnds<T> e;
+    e.s0 = c[0]; e.s1 = c[1]; e.s2 = c[2]; e.g0 = c[9]; e.g1 = c[10]; e.g2 = c[11];
+    e.y0 = y[0]; e.y3 = y[3];
+    return e;
+}
+template <typename T>
+__device__ __forceinline__ void spline_sample4(const T *__restrict__ m, const T *__restrict__ my, const TaskEnds<T> &te, const T (&x)[8],
+                                               T &px, T &py, T &pz, T &yw)
+{
+    const Pair2<T> *r = reinterpret_cast<const Pair2<T> *>(m), *ry = reinterpret_cast<const Pair2<T> *>(my);
+    const Pair2<T> r0 = r[0], r1 = r[1], y0 = ry[0], y1 = ry[1];
+    px = r0.a * te.s0; py = r0.a * te.s1; pz = r0.a * te.s2;
+    px = mp_fma(r0.b, x[0], px); py = mp_fma(r0.b, x[1], py); pz = mp_fma(r0.b, x[2], pz);
+    px = mp_fma(r1.a, x[3], px); py = mp_fma(r1.a, x[4], py); pz = mp_fma(r1.a, x[5], pz);
+    px = mp_fma(r1.b, te.g0, px); py = mp_fma(r1.b, te.g1, py); pz = mp_fma(r1.b, te.g2, pz);
+    yw = y0.a * te.y0;
+    yw = mp_fma(y0.b, x[6], yw);
+    yw = mp_fma(y1.a, x[7], yw);
+    yw = mp_fma(y1.b, te.y3, yw);
 }
 
 // LDS slice of one wave (bytes).  Layout (S = samples, e = sizeof(T)):
@@ -249,7 +283,12 @@ __device__ __forceinline__ void clearance_chunk(const AT &a, const BoxRec<T> *bo
     // running upper bound of the lane's squared clearance; -1 on lanes without a sample, so that `lb2 <= U32`
     // alone (one v_cmp, whose result is the ballot) says whether the lane needs a pair
     float U32 = valid ? __builtin_huge_valf() : -1.0f;
-    int qhead = 0, qcount = 0;  // wave-uniform
+    const unsigned int lane10 = (unsigned int)lane << 10, lane24 = (unsigned int)lane << 24;
+    (void)lane10; (void)lane24;
+    // Work queue: a LINEAR array of up to 128 entries, filled from the front.  An exact pass takes entries 0 .. 63 and moves
+    // what lies behind them (fewer than 64 entries) to the front, so a push needs no ring arithmetic: its slot is
+    // qcount + (needing lanes below this one), which v_mbcnt delivers with qcount as its start value.
+    int qcount = 0;  // wave-uniform
     MP_STAT_ADD(0, 1);
     if (SEED && ngroups > 1) {
         // Seed of the upper bound: the mover's centre lies in the mover and a box's centre in the box, so the scene
@@ -268,20 +307,23 @@ __device__ __forceinline__ void clearance_chunk(const AT &a, const BoxRec<T> *bo
         if (valid) U32 = ub * (1.0f + 4e-6f);
     }
 
-    // exact evaluation of up to 64 queued (sample, box) pairs, one per lane
-    auto drain = [&](int cnt) {
+    // exact evaluation of the first `cnt` <= 64 queued (sample, box) pairs, one per lane; `rest` entries behind them move
+    // to the front of the queue
+    auto drain = [&](int cnt, int rest) {
         MP_STAT_ADD(3, cnt); MP_STAT_ADD(4, 1);
         wave_lds_sync();
         const bool act = lane < cnt;
         unsigned long long key = ~0ull, oldk = 0ull;
         int kk = 0, bb = 0;
+        unsigned int moved = 0;
+        if (lane < rest) moved = Q16 ? (unsigned int)reinterpret_cast<const unsigned short *>(QUEUE)[64 + lane] : QUEUE[64 + lane];
         if (act) {
             if (Q16) {
-                const unsigned int e = reinterpret_cast<const unsigned short *>(QUEUE)[(qhead + lane) & 127];
+                const unsigned int e = reinterpret_cast<const unsigned short *>(QUEUE)[lane];
                 kk = (int)(e >> 10);
                 bb = (int)(e & 0x3ffu);
             } else {
-                const unsigned int e = QUEUE[(qhead + lane) & 127];
+                const unsigned int e = QUEUE[lane];
                 kk = (int)(e >> 24);
                 bb = (int)(e & 0xffffffu);
             }
@@ -312,6 +354,13 @@ __device__ __forceinline__ void clearance_chunk(const AT &a, const BoxRec<T> *bo
             }
 #endif
             if (ARGS) oldk = MINKEY[kk * KS];
+        }
+        if (rest > 0) {   // the queue reads of this pass were issued above; LDS operations of a wave complete in issue order
+            wave_lds_sync();
+            if (lane < rest) {
+                if (Q16) reinterpret_cast<unsigned short *>(QUEUE)[lane] = (unsigned short)moved;
+                else QUEUE[lane] = moved;
+            }
         }
         if (ARGS) {
             wave_lds_sync();
@@ -366,8 +415,8 @@ __device__ __forceinline__ void clearance_chunk(const AT &a, const BoxRec<T> *bo
         const unsigned long long m = __builtin_amdgcn_ballot_w64(need);
         if (need) {
             const int pos = __builtin_amdgcn_mbcnt_hi((unsigned int)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)m, 0u));
-            if (Q16) reinterpret_cast<unsigned short *>(QUEUE)[pos & 127] = (unsigned short)(((unsigned int)lane << 10) | (unsigned int)bi);
-            else QUEUE[pos & 127] = ((unsigned int)lane << 24) | (unsigned int)bi;
+            if (Q16) reinterpret_cast<unsigned short *>(QUEUE)[pos] = (unsigned short)(((unsigned int)lane << 10) | (unsigned int)bi);
+            else QUEUE[pos] = ((unsigned int)lane << 24) | (unsigned int)bi;
         }
         qcount = __builtin_popcountll(m);
     }
@@ -389,14 +438,13 @@ __device__ __forceinline__ void clearance_chunk(const AT &a, const BoxRec<T> *bo
             const unsigned long long m = __builtin_amdgcn_ballot_w64(need);
             if (m) {
                 if (need) {
-                    const int pos = __builtin_amdgcn_mbcnt_hi((unsigned int)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)m, 0u));
-                    if (Q16) reinterpret_cast<unsigned short *>(QUEUE)[(qhead + qcount + pos) & 127] = (unsigned short)(((unsigned int)lane << 10) | (unsigned int)idx);
-                    else QUEUE[(qhead + qcount + pos) & 127] = ((unsigned int)lane << 24) | (unsigned int)idx;
+                    const int pos = __builtin_amdgcn_mbcnt_hi((unsigned int)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)m, (unsigned int)qcount));
+                    if (Q16) reinterpret_cast<unsigned short *>(QUEUE)[pos] = (unsigned short)(lane10 | (unsigned int)idx);
+                    else QUEUE[pos] = lane24 | (unsigned int)idx;
                 }
                 qcount += __builtin_popcountll(m);
                 if (qcount >= 64) {
-                    drain(64);
-                    qhead = (qhead + 64) & 127;
+                    drain(64, qcount - 64);
                     qcount -= 64;
                 }
             }
@@ -410,7 +458,7 @@ __device__ __forceinline__ void clearance_chunk(const AT &a, const BoxRec<T> *bo
             push(bp.idx1 >= 0 && lb2.y <= U32, bp.idx1);   // against the bound as the first push may have refreshed it
         }
     }
-    if (qcount > 0) drain(qcount);
+    if (qcount > 0) drain(qcount, 0);
     wave_lds_sync();
 }
 
@@ -465,13 +513,15 @@ __global__ void __launch_bounds__(256, (eval_min_waves<T, GRAD, ROT, WV, NW>()))
             goal_tgt = a.goal_tgt;                                                                                         \
     T w[kNTerms];                                                                                                          \
     _Pragma("unroll") for (int wi_ = 0; wi_ < kNTerms; ++wi_) w[wi_] = a.w[wi_];                                           \
+    T w2[kNTerms];                                                                                                         \
+    _Pragma("unroll") for (int wi_ = 0; wi_ < kNTerms; ++wi_) w2[wi_] = a.w2[wi_];                                         \
     const T *M = a.M, *My = a.My, *tsched = a.tsched;                                                                      \
     const uint8_t *amask = a.amask;                                                                                        \
     const DevTask<T> &tk = a.tasks[t];                                                                                     \
     const BoxRec<T> *boxes = a.boxes + __builtin_amdgcn_readfirstlane(tk.box_begin);                                       \
     (void)S; (void)C; (void)Cy; (void)nf; (void)ff; (void)nyf; (void)D; (void)mask; (void)keep_n; (void)use_pref;          \
     (void)tail_start; (void)use_goal_target; (void)goal_tail_n; (void)last_cond; (void)du; (void)inv_du; (void)inv_h2;     \
-    (void)req; (void)pref; (void)appr_tgt; (void)goal_tgt; (void)w; (void)M; (void)My; (void)tsched; (void)amask;          \
+    (void)req; (void)pref; (void)appr_tgt; (void)goal_tgt; (void)w; (void)w2; (void)M; (void)My; (void)tsched; (void)amask;          \
     (void)tk; (void)boxes
     extern __shared__ __align__(16) unsigned char smem_raw[];
     int lane = threadIdx.x & 63;
@@ -557,8 +607,19 @@ __global__ void __launch_bounds__(256, (eval_min_waves<T, GRAD, ROT, WV, NW>()))
         {
         MP_LOCALS;
         const T *x = a.X + cand * D;
-        // ---- waypoint table W[j][0..2] = position rows, W[j][3] = yaw controls ----
-        {
+        if (C == 4 && Cy == 4 && ff == 1 && nf == 2 && nyf == 2) {
+            // the reference's default layout: waypoints in registers / scalar operands, no table (spline_sample4)
+            T xv[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) xv[i] = x[i];
+            const TaskEnds<T> te = load_task_ends<T>(tk);
+            for (int s = lane + 64 * wv; s < S; s += 64 * NW) {
+                T px, py, pz, yw;
+                spline_sample4(M + (size_t)s * 4, My + (size_t)s * 4, te, xv, px, py, pz, yw);
+                RF(s, kP0) = px; RF(s, kP1) = py; RF(s, kP2) = pz; RF(s, kYW) = yw;
+            }
+        } else {
+            // ---- waypoint table W[j][0..2] = position rows, W[j][3] = yaw controls ----
             const int rows = C > Cy ? C : Cy;
             for (int i = lane + 64 * wv; i < rows * 4; i += 64 * NW) {
                 const int j = i >> 2, col = i & 3;
@@ -570,14 +631,13 @@ __global__ void __launch_bounds__(256, (eval_min_waves<T, GRAD, ROT, WV, NW>()))
                 }
                 W[i] = v;
             }
-        }
-        MP_CAND_SYNC();
-
-        // ---- spline samples Q = M W (fixed fma chain over the waypoints) ----
-        for (int s = lane + 64 * wv; s < S; s += 64 * NW) {
-            T px, py, pz, yw;
-            spline_sample(M + (size_t)s * C, My + (size_t)s * Cy, C, Cy, W, px, py, pz, yw);
-            RF(s, kP0) = px; RF(s, kP1) = py; RF(s, kP2) = pz; RF(s, kYW) = yw;
+            MP_CAND_SYNC();
+            // ---- spline samples Q = M W (fixed fma chain over the waypoints) ----
+            for (int s = lane + 64 * wv; s < S; s += 64 * NW) {
+                T px, py, pz, yw;
+                spline_sample(M + (size_t)s * C, My + (size_t)s * Cy, C, Cy, W, px, py, pz, yw);
+                RF(s, kP0) = px; RF(s, kP1) = py; RF(s, kP2) = pz; RF(s, kYW) = yw;
+            }
         }
         MP_CAND_SYNC();
 
@@ -593,21 +653,20 @@ __global__ void __launch_bounds__(256, (eval_min_waves<T, GRAD, ROT, WV, NW>()))
             if (s + 1 < S) {
                 T ex = RF(s + 1, kP0) - px, ey = RF(s + 1, kP1) - py, ez = RF(s + 1, kP2) - pz;
                 T n, inv_n;
-                sqrt_rsqrt(ex * ex + ey * ey + ez * ez, n, inv_n);
+                sqrt_rsqrt(mp_fma(ez, ez, mp_fma(ey, ey, ex * ex)), n, inv_n);
                 t_len += n;
                 if (GRAD) RF(s, kSEGW) = n > T(0) ? w[0] * inv_n : T(0);  // w_len / |segment s|, reused by the reverse sweep
                 T dy = RF(s + 1, kYW) - yw;
                 T e = npmax0(tk.yaw_inc ? -dy : dy);
-                t_mono += e * e;
+                t_mono = mp_fma(e, e, t_mono);
             }
             if (s + 2 < S) {
-                T e = yw - T(2) * RF(s + 1, kYW) + RF(s + 2, kYW);
-                t_ys += e * e;
+                T e = mp_fma(T(-2), RF(s + 1, kYW), yw) + RF(s + 2, kYW);   // (2 y is exact: the same value as y - 2 y' + y'')
+                t_ys = mp_fma(e, e, t_ys);
             }
             {
-                T target = y0 + (y1 - y0) * tsched[s];
-                T e = yw - target;
-                t_sched += e * e;
+                T e = yw - mp_fma(y1 - y0, tsched[s], y0);
+                t_sched = mp_fma(e, e, t_sched);
             }
             if (S >= 3) {  // np.gradient(P, du): one-sided at the ends, central inside
                 const int lo = s == 0 ? 0 : s - 1, hi = s == S - 1 ? s : s + 1;
@@ -630,37 +689,35 @@ __global__ void __launch_bounds__(256, (eval_min_waves<T, GRAD, ROT, WV, NW>()))
         // ---- curvature, pass 2 (second np.gradient) ----
         if ((mask & (1u << 1)) && S >= 3) {
             const T eps = T(1e-9);
+            const T kc1 = w[1] * du, kc2 = kc1 * T(2), kc5 = kc1 * T(-5);
+            (void)kc2; (void)kc5;
             for (int s = lane + 64 * wv; s < S; s += 64 * NW) {
                 const T v1x = RF(s, kD1x), v1y = RF(s, kD1y), v1z = RF(s, kD1z);
                 const int lo = s == 0 ? 0 : s - 1, hi = s == S - 1 ? s : s + 1;
                 const T sc = (s == 0 || s == S - 1) ? inv_du : inv_h2;
                 const T v2x = (RF(hi, kD1x) - RF(lo, kD1x)) * sc, v2y = (RF(hi, kD1y) - RF(lo, kD1y)) * sc, v2z = (RF(hi, kD1z) - RF(lo, kD1z)) * sc;
                 T speed, inv_speed;
-                sqrt_rsqrt(v1x * v1x + v1y * v1y + v1z * v1z, speed, inv_speed);
-                T cx = v1y * v2z - v1z * v2y, cy = v1z * v2x - v1x * v2z, cz = v1x * v2y - v1y * v2x;
-                T cn2 = cx * cx + cy * cy + cz * cz;
+                sqrt_rsqrt(mp_fma(v1z, v1z, mp_fma(v1y, v1y, v1x * v1x)), speed, inv_speed);
+                // c = d1 x d2, every component one product and one fma
+                T cx = mp_fma(v1y, v2z, -(v1z * v2y)), cy = mp_fma(v1z, v2x, -(v1x * v2z)), cz = mp_fma(v1x, v2y, -(v1y * v2x));
+                T cn2 = mp_fma(cz, cz, mp_fma(cy, cy, cx * cx));
                 // kappa^2 speed = |c|^2 speed / max(speed, eps)^6 (|c| itself is never needed)
                 const T inv_sp = speed > eps ? inv_speed : T(1e9);
-                T inv_sp3 = inv_sp * inv_sp * inv_sp;
-                t_curv += (cn2 * (inv_sp3 * inv_sp3)) * speed;
+                const T inv_sp3 = inv_sp * inv_sp * inv_sp;
+                const T inv_sp6 = inv_sp3 * inv_sp3;
+                const T gs0 = cn2 * inv_sp6;          // |c|^2 / sp^6
+                t_curv = mp_fma(gs0, speed, t_curv);
                 if (GRAD) {
-                    // f = |c|^2 speed / sp^6 with c = d1 x d2; adjoints of d1 and d2
-                    const T inv_sp6 = inv_sp3 * inv_sp3;
-                    const T k = w[1] * du;
-                    const T f2 = k * T(2) * speed * inv_sp6;
+                    // f = |c|^2 speed / sp^6 with c = d1 x d2; adjoints of d1 and d2 (kc2 = 2 w_curv du)
+                    const T f2 = (kc2 * speed) * inv_sp6;
                     const T gcx = f2 * cx, gcy = f2 * cy, gcz = f2 * cz;
-                    T gs = cn2 * inv_sp6;
                     T q = T(0);
-                    if (speed > eps) {
-                        gs = gs + T(-6) * gs;  // explicit + through sp (= speed)
-                        q = k * gs * inv_sp;
-                    } else if (speed > T(0)) {
-                        q = k * gs * inv_speed;
-                    }
-                    RF(s, kA1x) = v2y * gcz - v2z * gcy + q * v1x;
-                    RF(s, kA1y) = v2z * gcx - v2x * gcz + q * v1y;
-                    RF(s, kA1z) = v2x * gcy - v2y * gcx + q * v1z;
-                    RF(s, kA2x) = gcy * v1z - gcz * v1y; RF(s, kA2y) = gcz * v1x - gcx * v1z; RF(s, kA2z) = gcx * v1y - gcy * v1x;
+                    if (speed > eps) q = (kc5 * gs0) * inv_sp;          // explicit + through sp (= speed): (1 - 6) |c|^2 / sp^6, kc5 = -5 w_curv du
+                    else if (speed > T(0)) q = (kc1 * gs0) * inv_speed;
+                    RF(s, kA1x) = mp_fma(v2y, gcz, mp_fma(-v2z, gcy, q * v1x));
+                    RF(s, kA1y) = mp_fma(v2z, gcx, mp_fma(-v2x, gcz, q * v1y));
+                    RF(s, kA1z) = mp_fma(v2x, gcy, mp_fma(-v2y, gcx, q * v1z));
+                    RF(s, kA2x) = mp_fma(gcy, v1z, -(gcz * v1y)); RF(s, kA2y) = mp_fma(gcz, v1x, -(gcx * v1z)); RF(s, kA2z) = mp_fma(gcx, v1y, -(gcy * v1x));
                 }
             }
         }
@@ -736,25 +793,26 @@ __global__ void __launch_bounds__(256, (eval_min_waves<T, GRAD, ROT, WV, NW>()))
             const T d = RF(k, kD);
             mc = d < mc ? d : mc;
             T gd = T(0);
+            // (w2 = 2 w: d(e^2) = 2 e de; every update of gd is one fma)
             if (mask & (1u << 3)) {
                 T e = npmax0(req - d);
-                t_safe += e * e;
-                gd -= w[3] * T(2) * e;
+                t_safe = mp_fma(e, e, t_safe);
+                if (GRAD) gd = mp_fma(-w2[3], e, gd);
             }
             if ((mask & (1u << 4)) && use_pref && k < keep_n) {
                 T e = npmax0(pref - d);
-                t_pref += e * e;
-                gd -= w[4] * T(2) * e;
+                t_pref = mp_fma(e, e, t_pref);
+                if (GRAD) gd = mp_fma(-w2[4], e, gd);
             }
             if (mask & (1u << 5)) {
                 if (k >= tail_start && k + 1 < Sp) {
                     T e = npmax0(RF(k + 1, kD) - d);
-                    t_reb += e * e;
-                    gd -= w[5] * T(2) * e;
+                    t_reb = mp_fma(e, e, t_reb);
+                    if (GRAD) gd = mp_fma(-w2[5], e, gd);
                 }
-                if (k - 1 >= tail_start && k - 1 >= 0) {
+                if (GRAD && k - 1 >= tail_start && k - 1 >= 0) {
                     T e = npmax0(d - RF(k - 1, kD));
-                    gd += w[5] * T(2) * e;
+                    gd = mp_fma(w2[5], e, gd);
                 }
             }
             if (k == Sp - 1) {
@@ -762,24 +820,24 @@ __global__ void __launch_bounds__(256, (eval_min_waves<T, GRAD, ROT, WV, NW>()))
                     T e = d - pref;
                     e = e > T(0) ? e : T(0);
                     t_gc = e * e;
-                    gd += w[6] * T(2) * e;
+                    if (GRAD) gd = mp_fma(w2[6], e, gd);
                 }
                 if ((mask & (1u << 7)) && use_goal_target) {
                     T e = d - goal_tgt;
                     t_gt = e * e;
-                    gd += w[7] * T(2) * e;
+                    if (GRAD) gd = mp_fma(w2[7], e, gd);
                 }
             }
             if (amask[k]) {
                 if (mask & (1u << 8)) {
                     T e = npmax0(appr_tgt - d);
-                    t_ac += e * e;
-                    gd -= w[8] * T(2) * e;
+                    t_ac = mp_fma(e, e, t_ac);
+                    if (GRAD) gd = mp_fma(-w2[8], e, gd);
                 }
                 if (mask & (1u << 9)) {
                     T e = npmax0(-d);
-                    t_acol += e * e;
-                    gd -= w[9] * T(2) * e;
+                    t_acol = mp_fma(e, e, t_acol);
+                    if (GRAD) gd = mp_fma(-w2[9], e, gd);
                 }
             }
             if (GRAD) RF(k, kGD) = gd;
@@ -799,19 +857,18 @@ __global__ void __launch_bounds__(256, (eval_min_waves<T, GRAD, ROT, WV, NW>()))
         MP_ARGS_REFRESH();
         {
         MP_LOCALS;
-        // ---- small closed-form terms, computed redundantly by every lane ----
-        if (mask & (1u << 10))
-            for (int j = 0; j < nf; ++j)
-                for (int c3 = 0; c3 < 3; ++c3) {
-                    T e = ((COMPACT || WIDE) ? a.X[cand * D + 3 * j + c3] : W[4 * (ff + j) + c3]) - tk.ctrl[ff + j][c3];
-                    t_via += e * e;
-                }
-        if (mask & (1u << 11))
-            for (int j = 0; j < Cy; ++j) {
-                // (five-wave instance: W is gone; the fixed yaw controls contribute exact zeros, like the reference's full sum)
-                T e = ((COMPACT || WIDE) ? ((j >= 1 && j <= nyf) ? a.X[cand * D + 3 * nf + (j - 1)] : tk.yaw_ctrl[j]) : W[4 * j + 3]) - tk.yaw_ctrl[j];
-                t_ydev += e * e;
-            }
+        // ---- deviation terms: lane o < D holds (x_o - its initial value)^2 of optimisation variable o (the fixed yaw controls
+        // of the reference's full sum contribute exact zeros); per-lane partial sums like the per-sample terms ----
+        if ((mask & ((1u << 10) | (1u << 11))) && lane < D && wv == 0) {
+            const T e = a.X[cand * D + lane] - tk.xref[lane];
+            const T e2 = e * e;
+            if (lane < 3 * nf) t_via = (mask & (1u << 10)) ? e2 : T(0);
+            else t_ydev = (mask & (1u << 11)) ? e2 : T(0);
+        }
+        if (FOLD) {
+            if (mask & (1u << 10)) part = mp_fma(w[10], t_via, part);
+            if (mask & (1u << 11)) part = mp_fma(w[11], t_ydev, part);
+        }
         // goal approach alignment: v = P[S-1] - P[first] (telescoped sum of the tail diffs)
         gn_first = S - goal_tail_n;
         gn_first = gn_first < 0 ? 0 : gn_first;
@@ -855,10 +912,8 @@ __global__ void __launch_bounds__(256, (eval_min_waves<T, GRAD, ROT, WV, NW>()))
             mc = RED[1];
             for (int v = 1; v < NW; ++v) {
                 jtot += RED[v * 2];
-                mc = lane_min(mc, RED[v * 2 + 1]);
+                mc = mp_min(mc, RED[v * 2 + 1]);
             }
-            if (mask & (1u << 10)) jtot += w[10] * t_via;
-            if (mask & (1u << 11)) jtot += w[11] * t_ydev;
             if (mask & (1u << 14)) jtot += w[14] * t_gn;
         } else if (!COMPACT && a.terms) {
             term[0] = (mask & 1u) ? wave_sum(t_len) : T(0);
@@ -871,8 +926,8 @@ __global__ void __launch_bounds__(256, (eval_min_waves<T, GRAD, ROT, WV, NW>()))
             term[7] = wave_sum(t_gt);
             term[8] = wave_sum(t_ac);
             term[9] = wave_sum(t_acol);
-            term[10] = t_via;
-            term[11] = t_ydev;
+            term[10] = wave_sum(t_via);
+            term[11] = wave_sum(t_ydev);
             term[12] = (mask & (1u << 12)) ? wave_sum(t_mono) : T(0);
             term[13] = (mask & (1u << 13)) ? wave_sum(t_sched) : T(0);
             term[14] = t_gn;
@@ -896,10 +951,10 @@ __global__ void __launch_bounds__(256, (eval_min_waves<T, GRAD, ROT, WV, NW>()))
                 if (mask & (1u << 7)) part += w[7] * t_gt;
                 if (mask & (1u << 8)) part += w[8] * t_ac;
                 if (mask & (1u << 9)) part += w[9] * t_acol;
+                if (mask & (1u << 10)) part = mp_fma(w[10], t_via, part);
+                if (mask & (1u << 11)) part = mp_fma(w[11], t_ydev, part);
             }
             jtot = wave_sum(part);
-            if (mask & (1u << 10)) jtot += w[10] * t_via;
-            if (mask & (1u << 11)) jtot += w[11] * t_ydev;
             if (mask & (1u << 14)) jtot += w[14] * t_gn;
         }
         if constexpr (!WIDE) mc = wave_min(mc);
@@ -932,9 +987,9 @@ __global__ void __launch_bounds__(256, (eval_min_waves<T, GRAD, ROT, WV, NW>()))
                     const T cp = s == S - 2 ? -inv_du : ((s <= S - 3) ? -inv_h2 : T(0));
                     const T c0 = s == 0 ? -inv_du : (s == S - 1 ? inv_du : T(0));
                     const int lo = s == 0 ? 0 : s - 1, hi = s == S - 1 ? s : s + 1;
-                    RF(s, kA1x) = RF(s, kA1x) + (cm * RF(lo, kA2x) + c0 * RF(s, kA2x) + cp * RF(hi, kA2x));
-                    RF(s, kA1y) = RF(s, kA1y) + (cm * RF(lo, kA2y) + c0 * RF(s, kA2y) + cp * RF(hi, kA2y));
-                    RF(s, kA1z) = RF(s, kA1z) + (cm * RF(lo, kA2z) + c0 * RF(s, kA2z) + cp * RF(hi, kA2z));
+                    RF(s, kA1x) = mp_fma(cm, RF(lo, kA2x), mp_fma(c0, RF(s, kA2x), mp_fma(cp, RF(hi, kA2x), RF(s, kA1x))));
+                    RF(s, kA1y) = mp_fma(cm, RF(lo, kA2y), mp_fma(c0, RF(s, kA2y), mp_fma(cp, RF(hi, kA2y), RF(s, kA1y))));
+                    RF(s, kA1z) = mp_fma(cm, RF(lo, kA2z), mp_fma(c0, RF(s, kA2z), mp_fma(cp, RF(hi, kA2z), RF(s, kA1z))));
                 }
             }
             MP_CAND_SYNC();
@@ -975,11 +1030,11 @@ __global__ void __launch_bounds__(256, (eval_min_waves<T, GRAD, ROT, WV, NW>()))
                 if (mask & 1u) {  // RF(i, kSEGW) = w_len / |P[i+1] - P[i]| from the forward pass
                     if (s >= 1) {
                         const T k = RF(s - 1, kSEGW);
-                        gx += k * (px - RF(s - 1, kP0)); gy += k * (py - RF(s - 1, kP1)); gz += k * (pz - RF(s - 1, kP2));
+                        gx = mp_fma(k, px - RF(s - 1, kP0), gx); gy = mp_fma(k, py - RF(s - 1, kP1), gy); gz = mp_fma(k, pz - RF(s - 1, kP2), gz);
                     }
                     if (s + 1 < S) {
-                        const T k = RF(s, kSEGW);
-                        gx -= k * (RF(s + 1, kP0) - px); gy -= k * (RF(s + 1, kP1) - py); gz -= k * (RF(s + 1, kP2) - pz);
+                        const T k = -RF(s, kSEGW);
+                        gx = mp_fma(k, RF(s + 1, kP0) - px, gx); gy = mp_fma(k, RF(s + 1, kP1) - py, gy); gz = mp_fma(k, RF(s + 1, kP2) - pz, gz);
                     }
                 }
                 if (curv) {
@@ -987,32 +1042,31 @@ __global__ void __launch_bounds__(256, (eval_min_waves<T, GRAD, ROT, WV, NW>()))
                     const T cp = s == S - 2 ? -inv_du : ((s <= S - 3) ? -inv_h2 : T(0));
                     const T c0 = s == 0 ? -inv_du : (s == S - 1 ? inv_du : T(0));
                     const int lo = s == 0 ? 0 : s - 1, hi = s == S - 1 ? s : s + 1;
-                    gx += cm * RF(lo, kA1x) + c0 * RF(s, kA1x) + cp * RF(hi, kA1x);
-                    gy += cm * RF(lo, kA1y) + c0 * RF(s, kA1y) + cp * RF(hi, kA1y);
-                    gz += cm * RF(lo, kA1z) + c0 * RF(s, kA1z) + cp * RF(hi, kA1z);
+                    gx = mp_fma(cm, RF(lo, kA1x), mp_fma(c0, RF(s, kA1x), mp_fma(cp, RF(hi, kA1x), gx)));
+                    gy = mp_fma(cm, RF(lo, kA1y), mp_fma(c0, RF(s, kA1y), mp_fma(cp, RF(hi, kA1y), gy)));
+                    gz = mp_fma(cm, RF(lo, kA1z), mp_fma(c0, RF(s, kA1z), mp_fma(cp, RF(hi, kA1z), gz)));
                 }
                 if (s == S - 1) { gx += gnx; gy += gny; gz += gnz; }
                 if (s == gn_first) { gx -= gnx; gy -= gny; gz -= gnz; }
                 if ((mask & 4u) && S >= 3) {  // yaw smoothness: e_i = y_i - 2 y_{i+1} + y_{i+2}
-                    const T k2 = w[2] * T(2);
-                    if (s + 2 < S) gw += k2 * (yw - T(2) * RF(s + 1, kYW) + RF(s + 2, kYW));
-                    if (s >= 1 && s + 1 < S) gw -= T(2) * k2 * (RF(s - 1, kYW) - T(2) * yw + RF(s + 1, kYW));
-                    if (s >= 2) gw += k2 * (RF(s - 2, kYW) - T(2) * RF(s - 1, kYW) + yw);
+                    const T k2 = w2[2], k4 = T(-2) * k2;
+                    if (s + 2 < S) gw = mp_fma(k2, mp_fma(T(-2), RF(s + 1, kYW), yw) + RF(s + 2, kYW), gw);
+                    if (s >= 1 && s + 1 < S) gw = mp_fma(k4, mp_fma(T(-2), yw, RF(s - 1, kYW)) + RF(s + 1, kYW), gw);
+                    if (s >= 2) gw = mp_fma(k2, mp_fma(T(-2), RF(s - 1, kYW), RF(s - 2, kYW)) + yw, gw);
                 }
                 if (mask & (1u << 12)) {
-                    const T sg = tk.yaw_inc ? T(-1) : T(1);
+                    const T ksg = tk.yaw_inc ? -w2[12] : w2[12];
                     if (s >= 1) {
                         T dy = yw - RF(s - 1, kYW);
-                        gw += w[12] * T(2) * npmax0(tk.yaw_inc ? -dy : dy) * sg;
+                        gw = mp_fma(ksg, npmax0(tk.yaw_inc ? -dy : dy), gw);
                     }
                     if (s + 1 < S) {
                         T dy = RF(s + 1, kYW) - yw;
-                        gw -= w[12] * T(2) * npmax0(tk.yaw_inc ? -dy : dy) * sg;
+                        gw = mp_fma(-ksg, npmax0(tk.yaw_inc ? -dy : dy), gw);
                     }
                 }
                 if (mask & (1u << 13)) {
-                    T target = y0 + (y1 - y0) * tsched[s];
-                    gw += w[13] * T(2) * (yw - target);
+                    gw = mp_fma(w2[13], yw - mp_fma(y1 - y0, tsched[s], y0), gw);
                 }
                 RF(s, kGX) = gx; RF(s, kGY) = gy; RF(s, kGZ) = gz; RF(s, kGW) = gw;   // slots dead by now (see RecField)
             }
@@ -1059,13 +1113,7 @@ __global__ void __launch_bounds__(256, (eval_min_waves<T, GRAD, ROT, WV, NW>()))
                     if (o < D && sg8 == 0) RED[wv * RS + o] = acc;   // this wave's share of the samples
                 } else if (o < D && sg8 == 0) {
                     const bool is_pos = o < 3 * nf;
-                    const int jj = is_pos ? o / 3 : o - 3 * nf;
-                    const int comp = is_pos ? o - 3 * jj : 0;
-                    if (is_pos) {
-                        if (mask & (1u << 10)) acc += w[10] * T(2) * ((FIVE ? a.X[cand * D + o] : W[4 * (ff + jj) + comp]) - tk.ctrl[ff + jj][comp]);
-                    } else {
-                        if (mask & (1u << 11)) acc += w[11] * T(2) * ((FIVE ? a.X[cand * D + o] : W[4 * (1 + jj) + 3]) - tk.yaw_ctrl[1 + jj]);
-                    }
+                    if (mask & (1u << (is_pos ? 10 : 11))) acc = mp_fma(is_pos ? w2[10] : w2[11], a.X[cand * D + o] - tk.xref[o], acc);
                     gout[o] = acc;
                 }
             }
@@ -1076,13 +1124,7 @@ __global__ void __launch_bounds__(256, (eval_min_waves<T, GRAD, ROT, WV, NW>()))
                     T acc = RED[o];
                     for (int v = 1; v < NW; ++v) acc += RED[v * RS + o];
                     const bool is_pos = o < 3 * nf;
-                    const int jj = is_pos ? o / 3 : o - 3 * nf;
-                    const int comp = is_pos ? o - 3 * jj : 0;
-                    if (is_pos) {
-                        if (mask & (1u << 10)) acc += w[10] * T(2) * (a.X[cand * D + o] - tk.ctrl[ff + jj][comp]);
-                    } else {
-                        if (mask & (1u << 11)) acc += w[11] * T(2) * (a.X[cand * D + o] - tk.yaw_ctrl[1 + jj]);
-                    }
+                    if (mask & (1u << (is_pos ? 10 : 11))) acc = mp_fma(is_pos ? w2[10] : w2[11], a.X[cand * D + o] - tk.xref[o], acc);
                     gout[o] = acc;
                 }
             }
@@ -1147,27 +1189,41 @@ __global__ void __launch_bounds__(256, (ROT == 2 ? 2 : MP_CLR_WAVES)) clearance_
         const BoxRec32 *groups = a.groups + 2 * __builtin_amdgcn_readfirstlane(tk.group_begin);
         const int ngroups = __builtin_amdgcn_readfirstlane(tk.group_count);
         const int n_wide = __builtin_amdgcn_readfirstlane(tk.n_wide);
-        {   // waypoint table, as in eval_kernel
-            const int rows = C > Cy ? C : Cy;
-            for (int i = lane; i < rows * 4; i += 64) {
-                const int j = i >> 2, col = i & 3;
-                T v = T(0);
-                if (col < 3) {
-                    if (j < C) v = (j >= ff && j < ff + nf) ? x[3 * (j - ff) + col] : tk.ctrl[j][col];
-                } else if (j < Cy) {
-                    v = (j >= 1 && j <= nyf) ? x[3 * nf + (j - 1)] : tk.yaw_ctrl[j];
-                }
-                W[i] = v;
-            }
-        }
-        wave_lds_sync();
         const int k = k0 + lane;
-        if (k < a.Sp) {   // this lane's sample, same fma chain as eval_kernel
-            const int s = sample_of(a, k);
-            T px, py, pz, yw;
-            spline_sample(a.M + (size_t)s * C, a.My + (size_t)s * Cy, C, Cy, W, px, py, pz, yw);
-            T *r = REC + lane * kChunkRec;
-            r[kP0] = px; r[kP1] = py; r[kP2] = pz; r[kYW] = yw;
+        if (C == 4 && Cy == 4 && ff == 1 && nf == 2 && nyf == 2) {   // default layout: no waypoint table (eval_kernel, spline_sample4)
+            T xv[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) xv[i] = x[i];
+            const TaskEnds<T> te = load_task_ends<T>(tk);
+            if (k < a.Sp) {
+                const int s = sample_of(a, k);
+                T px, py, pz, yw;
+                spline_sample4(a.M + (size_t)s * 4, a.My + (size_t)s * 4, te, xv, px, py, pz, yw);
+                T *r = REC + lane * kChunkRec;
+                r[kP0] = px; r[kP1] = py; r[kP2] = pz; r[kYW] = yw;
+            }
+        } else {
+            {   // waypoint table, as in eval_kernel
+                const int rows = C > Cy ? C : Cy;
+                for (int i = lane; i < rows * 4; i += 64) {
+                    const int j = i >> 2, col = i & 3;
+                    T v = T(0);
+                    if (col < 3) {
+                        if (j < C) v = (j >= ff && j < ff + nf) ? x[3 * (j - ff) + col] : tk.ctrl[j][col];
+                    } else if (j < Cy) {
+                        v = (j >= 1 && j <= nyf) ? x[3 * nf + (j - 1)] : tk.yaw_ctrl[j];
+                    }
+                    W[i] = v;
+                }
+            }
+            wave_lds_sync();
+            if (k < a.Sp) {   // this lane's sample, same fma chain as eval_kernel
+                const int s = sample_of(a, k);
+                T px, py, pz, yw;
+                spline_sample(a.M + (size_t)s * C, a.My + (size_t)s * Cy, C, Cy, W, px, py, pz, yw);
+                T *r = REC + lane * kChunkRec;
+                r[kP0] = px; r[kP1] = py; r[kP2] = pz; r[kYW] = yw;
+            }
         }
         wave_lds_sync();
         clearance_chunk<T, ROT, true, true, kChunkRec, 1, 1, false, ARGS>(a, boxes, boxes32, a.pairs + __builtin_amdgcn_readfirstlane(tk.spair_begin), groups, ngroups,

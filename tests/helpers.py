@@ -57,6 +57,21 @@ def rel_err(got, ref, floor=1e-12):
     return np.where(np.isfinite(e), e, 0.0)
 
 
+# Scale of a gradient row for relative errors.  A row whose true gradient vanishes by symmetry (x0 = the straight line through
+# free space: the contributions of neighbouring samples cancel) holds only the rounding noise of that cancellation on both
+# sides — ~1e-16 of the cancelling summands, which are O(w_len) ... O(1e2) per sample, i.e. up to ~1e-14 absolute after the
+# M^T g sum over the samples — so the row's own maximum is no scale for it.  Entries of non-vanishing gradients of these
+# problems are 1e0 ... 1e5; the floor below is four orders under the smallest of them.
+GRAD_FLOOR = 1e-4
+
+
+def grad_err(got, ref):
+    """Largest row-wise relative error of a gradient: |got - ref| / max(max|ref row|, GRAD_FLOOR)."""
+    got, ref = np.asarray(got, dtype=float), np.asarray(ref, dtype=float)
+    scale = np.maximum(np.abs(ref).max(axis=1, keepdims=True), GRAD_FLOOR)
+    return (np.abs(got - ref) / scale).max()
+
+
 def with_rotated_statics(prob, seed=0, keep_first=True):
     """Same problem with every static box (but the first: the table) turned about z by a random angle:
     rows grow to 8 columns, (z, w) of the yaw-only quaternion appended."""
@@ -104,7 +119,6 @@ def assert_same_gradient(got, want, prob, dtype=np.float64):
     (DESIGN.md 4), whose sums are added in a different order (1e-12 of the row's largest entry)."""
     if prob.n_samples > 176:
         got, want = np.asarray(got, dtype=float), np.asarray(want, dtype=float)
-        scale = np.maximum(np.abs(want).max(axis=1, keepdims=True), 1e-6)
-        assert (np.abs(got - want) / scale).max() < (1e-12 if dtype is np.float64 else 1e-4)
+        assert grad_err(got, want) < (1e-12 if dtype is np.float64 else 1e-4)
     else:
         np.testing.assert_array_equal(got, want)

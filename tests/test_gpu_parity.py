@@ -24,11 +24,9 @@ def native():
 
 
 def _grad_err(got, ref):
-    """Row-wise relative error.  A row whose true gradient vanishes (x0 = straight line through free space: every
-    term cancels) holds rounding noise of ~1e-16 on both sides, so the scale has an absolute floor of 1e-6
-    (gradient entries of these problems are 1e0 ... 1e5)."""
-    scale = np.maximum(np.abs(ref).max(axis=1, keepdims=True), 1e-6)
-    return (np.abs(got - ref) / scale).max()
+    """Row-wise relative error with the absolute floor of tests/helpers.py (GRAD_FLOOR: a row whose true gradient vanishes
+    holds the rounding noise of cancelling O(1) ... O(1e2) summands on both sides)."""
+    return H.grad_err(got, ref)
 
 
 def _compare(out, ref, dtype, exact_dist=True):

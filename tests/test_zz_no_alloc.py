@@ -117,7 +117,7 @@ def test_noalloc_with_tasks_rotations_and_the_wide_instance(shape):
             c_g, c_r = got["cost"][~bad].double(), ref["cost"][~bad].double()
             assert float(((c_g - c_r).abs() / c_r.abs().clamp_min(1e-12)).max()) <= tol
             g_g, g_r = got["grad"][~bad].double(), ref["grad"][~bad].double()
-            scale = g_r.abs().amax(dim=1, keepdim=True).clamp_min(1e-6)
+            scale = g_r.abs().amax(dim=1, keepdim=True).clamp_min(H.GRAD_FLOOR)
             assert float(((g_g - g_r).abs() / scale).max()) <= (1e-11 if dtype is np.float64 else 1e-4)
         ctx.close()
 

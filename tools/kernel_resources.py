@@ -39,5 +39,5 @@ out = ["# Resource usage of every kernel in libmp_hip.so (hipcc -S of motion_pla
 for (_, v), d in zip(rows, names):
     d = re.sub(r"\(.*$", "", d).replace("void ", "").replace("mp::", "")
     out.append(f"{d:58s} {v.get('v', -1):5d} {v.get('s', -1):5d} {v.get('sc', -1):9d} {v.get('o', -1):10d} {v.get('c', -1):7d}")
-(ROOT / "profiles" / "r02_kernel_resources.txt").write_text("\n".join(out) + "\n")
+(ROOT / "profiles" / (sys.argv[1] if len(sys.argv) > 1 else "r03_kernel_resources.txt")).write_text("\n".join(out) + "\n")
 print("\n".join(out))
