@@ -152,6 +152,15 @@ __device__ __forceinline__ void spline_sample(const T *__restrict__ m, const T *
 // The reference's default layout (n_vias = 2, combined_4d: four waypoints, the middle two free, two free yaw controls):
 // the waypoints never go through LDS.  Fixed rows come from the task record (wave-uniform: scalar operands), the free
 // ones are the candidate's x itself, read by every lane from the same 64 bytes.  Same fma chain, same bits.
+// A wave-uniform value of a table that is read-only for the launch (task records, problem constants), read through the
+// constant address space: it arrives over the scalar data path (s_load: a fraction of the latency of a vector load whose
+// 64 lanes ask for the same address, no vector register) instead of global_load + v_readfirstlane.
+template <typename U> __device__ __forceinline__ U ldu(const U *p)
+{
+    typedef const U __attribute__((address_space(4))) *CPtr;
+    return *(CPtr)(unsigned long long)p;
+}
+
 template <typename T> struct TaskEnds { T s0, s1, s2, g0, g1, g2, y0, y3; };   // first / last waypoint, first / last yaw control
 // read through the constant address space: the task table is read-only for the launch and the task is wave-uniform, so
 // the eight values arrive over the scalar data path and stay scalar operands of the fma chain
@@ -518,7 +527,7 @@ __global__ void __launch_bounds__(256, (eval_min_waves<T, GRAD, ROT, WV, NW>()))
     const T *M = a.M, *My = a.My, *tsched = a.tsched;                                                                      \
     const uint8_t *amask = a.amask;                                                                                        \
     const DevTask<T> &tk = a.tasks[t];                                                                                     \
-    const BoxRec<T> *boxes = a.boxes + __builtin_amdgcn_readfirstlane(tk.box_begin);                                       \
+    const BoxRec<T> *boxes = a.boxes + ldu(&tk.box_begin);                                       \
     (void)S; (void)C; (void)Cy; (void)nf; (void)ff; (void)nyf; (void)D; (void)mask; (void)keep_n; (void)use_pref;          \
     (void)tail_start; (void)use_goal_target; (void)goal_tail_n; (void)last_cond; (void)du; (void)inv_du; (void)inv_h2;     \
     (void)req; (void)pref; (void)appr_tgt; (void)goal_tgt; (void)w; (void)w2; (void)M; (void)My; (void)tsched; (void)amask;          \
@@ -647,7 +656,8 @@ __global__ void __launch_bounds__(256, (eval_min_waves<T, GRAD, ROT, WV, NW>()))
         {
         MP_LOCALS;
         // ---- per-sample geometric terms, pass 1 ----
-        const T y0 = tk.yaw_ctrl[0], y1 = tk.yaw_ctrl[Cy - 1];
+        const T y0 = ldu(&tk.yaw_ctrl[0]), y1 = ldu(&tk.yaw_ctrl[Cy - 1]);
+        const int yaw_inc = ldu(&tk.yaw_inc);
         for (int s = lane + 64 * wv; s < S; s += 64 * NW) {
             const T px = RF(s, kP0), py = RF(s, kP1), pz = RF(s, kP2), yw = RF(s, kYW);
             if (s + 1 < S) {
@@ -657,7 +667,7 @@ __global__ void __launch_bounds__(256, (eval_min_waves<T, GRAD, ROT, WV, NW>()))
                 t_len += n;
                 if (GRAD) RF(s, kSEGW) = n > T(0) ? w[0] * inv_n : T(0);  // w_len / |segment s|, reused by the reverse sweep
                 T dy = RF(s + 1, kYW) - yw;
-                T e = npmax0(tk.yaw_inc ? -dy : dy);
+                T e = npmax0(yaw_inc ? -dy : dy);
                 t_mono = mp_fma(e, e, t_mono);
             }
             if (s + 2 < S) {
@@ -745,12 +755,12 @@ __global__ void __launch_bounds__(256, (eval_min_waves<T, GRAD, ROT, WV, NW>()))
                 if (a.dist) a.dist[cand * a.Sp + k] = d;
             }
         } else if (MODEL == 1) {
-            const BoxRec32 *boxes32 = a.boxes32 + __builtin_amdgcn_readfirstlane(tk.sbox_begin);
-            const BoxRec32 *groups = a.groups + 2 * __builtin_amdgcn_readfirstlane(tk.group_begin);
-            const int ngroups = __builtin_amdgcn_readfirstlane(tk.group_count);
-            const int n_wide = __builtin_amdgcn_readfirstlane(tk.n_wide);
+            const BoxRec32 *boxes32 = a.boxes32 + ldu(&tk.sbox_begin);
+            const BoxRec32 *groups = a.groups + 2 * ldu(&tk.group_begin);
+            const int ngroups = ldu(&tk.group_count);
+            const int n_wide = ldu(&tk.n_wide);
             for (int k0 = 0; k0 < Sp; k0 += 64) {
-                clearance_chunk<T, ROT, false, false, NREC, KS, AS, COMPACT, GRAD>(a, boxes, boxes32, a.pairs + __builtin_amdgcn_readfirstlane(tk.spair_begin), groups,
+                clearance_chunk<T, ROT, false, false, NREC, KS, AS, COMPACT, GRAD>(a, boxes, boxes32, a.pairs + ldu(&tk.spair_begin), groups,
                                                                           ngroups, n_wide, lane, k0, Sp, REC, MINKEY + k0 * KS, ARG + k0 * AS, QUEUE);
                 const int k = k0 + lane;
                 if (k < Sp) {
@@ -768,7 +778,7 @@ __global__ void __launch_bounds__(256, (eval_min_waves<T, GRAD, ROT, WV, NW>()))
             for (int k = lane + 64 * wv; k < Sp; k += 64 * NW) {
                 const int s = sample_of(a, k);
                 int arg = -1;
-                const T d = point_distance(RF(s, kP0), RF(s, kP1), RF(s, kP2), boxes, __builtin_amdgcn_readfirstlane(tk.box_count), a.radius, ROT != 0, ROT == 2 ? a.tilt : nullptr, arg);
+                const T d = point_distance(RF(s, kP0), RF(s, kP1), RF(s, kP2), boxes, ldu(&tk.box_count), a.radius, ROT != 0, ROT == 2 ? a.tilt : nullptr, arg);
                 RF(k, kD) = d;
                 if (GRAD) ARG[k] = arg;
                 if (a.dist) a.dist[cand * a.Sp + k] = d;
@@ -872,14 +882,14 @@ __global__ void __launch_bounds__(256, (eval_min_waves<T, GRAD, ROT, WV, NW>()))
         // goal approach alignment: v = P[S-1] - P[first] (telescoped sum of the tail diffs)
         gn_first = S - goal_tail_n;
         gn_first = gn_first < 0 ? 0 : gn_first;
-        if ((mask & (1u << 14)) && tk.has_normal && S >= 3 && gn_first < S - 1) {
+        if ((mask & (1u << 14)) && ldu(&tk.has_normal) && S >= 3 && gn_first < S - 1) {
             T vx = RF(S - 1, kP0) - RF(gn_first, kP0), vy = RF(S - 1, kP1) - RF(gn_first, kP1), vz = RF(S - 1, kP2) - RF(gn_first, kP2);
             T n, inv_n;
             sqrt_rsqrt(vx * vx + vy * vy + vz * vz, n, inv_n);
             if (!(n < T(1e-12))) {
                 T ux = vx * inv_n, uy = vy * inv_n, uz = vz * inv_n;
                 if (ux != T(0) || uy != T(0) || uz != T(0)) {
-                    const T sx = tk.normal[0], sy = tk.normal[1], sz = tk.normal[2];
+                    const T sx = ldu(&tk.normal[0]), sy = ldu(&tk.normal[1]), sz = ldu(&tk.normal[2]);
                     T c = ux * -sx + uy * -sy + uz * -sz;
                     T cc = c < T(-1) ? T(-1) : (c > T(1) ? T(1) : c);
                     T e = T(1) - cc;
@@ -999,7 +1009,7 @@ __global__ void __launch_bounds__(256, (eval_min_waves<T, GRAD, ROT, WV, NW>()))
             {
             MP_LOCALS;
             const bool curv = (mask & 2u) && S >= 3;
-            const T y0 = tk.yaw_ctrl[0], y1 = tk.yaw_ctrl[Cy - 1];
+            const T y0 = ldu(&tk.yaw_ctrl[0]), y1 = ldu(&tk.yaw_ctrl[Cy - 1]);
             // (3) gather every contribution to gP[s], gyaw[s]
             for (int s = lane + 64 * wv; s < S; s += 64 * NW) {
                 T gx = T(0), gy = T(0), gz = T(0), gw = T(0);
@@ -1055,14 +1065,15 @@ __global__ void __launch_bounds__(256, (eval_min_waves<T, GRAD, ROT, WV, NW>()))
                     if (s >= 2) gw = mp_fma(k2, mp_fma(T(-2), RF(s - 1, kYW), RF(s - 2, kYW)) + yw, gw);
                 }
                 if (mask & (1u << 12)) {
-                    const T ksg = tk.yaw_inc ? -w2[12] : w2[12];
+                    const int yaw_inc = ldu(&tk.yaw_inc);
+                    const T ksg = yaw_inc ? -w2[12] : w2[12];
                     if (s >= 1) {
                         T dy = yw - RF(s - 1, kYW);
-                        gw = mp_fma(ksg, npmax0(tk.yaw_inc ? -dy : dy), gw);
+                        gw = mp_fma(ksg, npmax0(yaw_inc ? -dy : dy), gw);
                     }
                     if (s + 1 < S) {
                         T dy = RF(s + 1, kYW) - yw;
-                        gw = mp_fma(-ksg, npmax0(tk.yaw_inc ? -dy : dy), gw);
+                        gw = mp_fma(-ksg, npmax0(yaw_inc ? -dy : dy), gw);
                     }
                 }
                 if (mask & (1u << 13)) {
@@ -1184,11 +1195,11 @@ __global__ void __launch_bounds__(256, (ROT == 2 ? 2 : MP_CLR_WAVES)) clearance_
         const int t = __builtin_amdgcn_readfirstlane((int)tl);
         const DevTask<T> &tk = a.tasks[t];
         const T *x = a.X + cand * D;
-        const BoxRec<T> *boxes = a.boxes + __builtin_amdgcn_readfirstlane(tk.box_begin);
-        const BoxRec32 *boxes32 = a.boxes32 + __builtin_amdgcn_readfirstlane(tk.sbox_begin);
-        const BoxRec32 *groups = a.groups + 2 * __builtin_amdgcn_readfirstlane(tk.group_begin);
-        const int ngroups = __builtin_amdgcn_readfirstlane(tk.group_count);
-        const int n_wide = __builtin_amdgcn_readfirstlane(tk.n_wide);
+        const BoxRec<T> *boxes = a.boxes + ldu(&tk.box_begin);
+        const BoxRec32 *boxes32 = a.boxes32 + ldu(&tk.sbox_begin);
+        const BoxRec32 *groups = a.groups + 2 * ldu(&tk.group_begin);
+        const int ngroups = ldu(&tk.group_count);
+        const int n_wide = ldu(&tk.n_wide);
         const int k = k0 + lane;
         if (C == 4 && Cy == 4 && ff == 1 && nf == 2 && nyf == 2) {   // default layout: no waypoint table (eval_kernel, spline_sample4)
             T xv[8];
@@ -1226,7 +1237,7 @@ __global__ void __launch_bounds__(256, (ROT == 2 ? 2 : MP_CLR_WAVES)) clearance_
             }
         }
         wave_lds_sync();
-        clearance_chunk<T, ROT, true, true, kChunkRec, 1, 1, false, ARGS>(a, boxes, boxes32, a.pairs + __builtin_amdgcn_readfirstlane(tk.spair_begin), groups, ngroups,
+        clearance_chunk<T, ROT, true, true, kChunkRec, 1, 1, false, ARGS>(a, boxes, boxes32, a.pairs + ldu(&tk.spair_begin), groups, ngroups,
                                                        n_wide, lane, k0, a.Sp, REC, MINKEY, ARG, QUEUE);
         if (k < a.Sp) {
             a.pre_d[cand * a.Sp + k] = key_to_distance<T>(MINKEY[lane]);
