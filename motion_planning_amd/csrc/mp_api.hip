@@ -545,12 +545,18 @@ int launch_eval(mp_ctx *ctx, long long n, const void *X, const int32_t *task_of,
     a.w_elems = mp::w_elems_for(c.n_ctrl, c.n_yaw_ctrl);
     a.lds_per_wave = mp::lds_bytes_per_wave(c.n_samples, (int)sizeof(T), grad != nullptr, a.w_elems);
     a.n_tasks = ctx->n_tasks;
-    for (int i = 0; i < MP_NTERMS; ++i) { a.w[i] = (T)c.weights[i]; a.w2[i] = a.w[i] * T(2); }
+    for (int i = 0; i < MP_NTERMS; ++i) {
+        a.w[i] = (T)c.weights[i];
+        a.w2[i] = a.w[i] * T(2);
+        a.wf[i] = (c.term_mask & (1u << i)) ? a.w[i] : T(0);
+    }
     a.req = (T)c.required_clearance; a.pref = (T)c.preferred_clearance; a.appr_tgt = (T)c.approach_target;
     a.goal_tgt = (T)c.goal_clearance_target; a.radius = (T)c.point_radius;
     a.ax = (T)c.half_extents[0]; a.ay = (T)c.half_extents[1]; a.az = (T)c.half_extents[2];
     a.trig = mp::trig_table<T>();
     a.du = T(1) / (T)(c.n_samples - 1); a.inv_du = T(1) / a.du; a.inv_h2 = T(1) / (T(2) * a.du);
+    a.wf[1] = c.n_samples >= 3 ? a.wf[1] * a.du : T(0);   // curvature: the sum is weighted with w_curv du
+    if (c.n_samples < 3) a.wf[2] = T(0);
     a.idx_safe = (const int *)ctx->d_idx.p; a.inv_idx = (const int *)ctx->d_inv.p; a.idx_identity = ctx->idx_identity; a.amask = (const uint8_t *)ctx->d_mask.p;
     a.M = (const T *)ctx->d_M.p; a.My = (const T *)ctx->d_My.p; a.tsched = (const T *)ctx->d_tsched.p;
     a.tasks = (const mp::DevTask<T> *)ctx->d_tasks.p; a.boxes = (const mp::BoxRec<T> *)ctx->boxes.p;

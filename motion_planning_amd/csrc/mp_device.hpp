@@ -812,14 +812,22 @@ __device__ __forceinline__ int lane_min_fast(int a, int b) { return b < a ? b : 
 // cost has its NaNs replaced by +inf before the reduction): one v_min instead of a compare and two selects
 __device__ __forceinline__ float lane_min_fast(float a, float b) { return __builtin_fminf(a, b); }
 __device__ __forceinline__ double lane_min_fast(double a, double b) { return __builtin_fmin(a, b); }
+// cross-lane move whose every lane has a source (quad permutations, row mirrors): no `old` value to preserve, so no
+// register copy in front of the DPP move
+template <int CTRL> __device__ __forceinline__ int dpp_full(int v) { return __builtin_amdgcn_mov_dpp(v, CTRL, 0xf, 0xf, false); }
+template <int CTRL> __device__ __forceinline__ float dpp_full(float v) { return __int_as_float(dpp_full<CTRL>(__float_as_int(v))); }
+template <int CTRL> __device__ __forceinline__ double dpp_full(double v)
+{
+    return __hiloint2double(dpp_full<CTRL>(__double2hiint(v)), dpp_full<CTRL>(__double2loint(v)));
+}
 template <typename T> __device__ __forceinline__ T wave_min(T v)
 {
-    v = lane_min_fast(v, dpp_mov<0xB1, 0xf, false>(v));
-    v = lane_min_fast(v, dpp_mov<0x4E, 0xf, false>(v));
-    v = lane_min_fast(v, dpp_mov<0x141, 0xf, false>(v));
-    v = lane_min_fast(v, dpp_mov<0x140, 0xf, false>(v));
-    v = lane_min_fast(v, dpp_mov<0x142, 0xa, false>(v));
-    v = lane_min_fast(v, dpp_mov<0x143, 0xc, false>(v));
+    v = lane_min_fast(v, dpp_full<0xB1>(v));    // quad_perm [1,0,3,2]
+    v = lane_min_fast(v, dpp_full<0x4E>(v));    // quad_perm [2,3,0,1]
+    v = lane_min_fast(v, dpp_full<0x141>(v));   // row_half_mirror
+    v = lane_min_fast(v, dpp_full<0x140>(v));   // row_mirror
+    v = lane_min_fast(v, dpp_mov<0x142, 0xa, false>(v));   // row_bcast:15 into rows 1 and 3 (the other rows keep their value)
+    v = lane_min_fast(v, dpp_mov<0x143, 0xc, false>(v));   // row_bcast:31 into rows 2 and 3
     return read_lane63(v);
 }
 

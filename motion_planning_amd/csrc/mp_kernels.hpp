@@ -75,6 +75,9 @@ template <typename T> struct EvalArgs {
     int n_tasks;
     T w[kNTerms];
     T w2[kNTerms];     // 2 w[i] (exact): the factor of every d(e^2) in the reverse sweep
+    T wf[kNTerms];     // w[i] where the term is in the objective (term_mask), 0 elsewhere; wf[1] = w_curv du.  What the launches
+                       // without a term breakdown fold their partial sums with: one fma per term and no mask test.  (A term that
+                       // is masked off keeps a zero or finite partial sum, so 0 * t adds nothing.)
     T req, pref, appr_tgt, goal_tgt, radius, ax, ay, az;
     TrigTab<T> trig;        // constants of yaw_rot (mp_device.hpp)
     T du, inv_du, inv_h2;   // 1/(S-1), 1/du, 1/(2 du) in T arithmetic (host: the same correctly rounded divisions)
@@ -530,13 +533,15 @@ __global__ void __launch_bounds__(256, (eval_min_waves<T, GRAD, ROT, WV, NW>()))
     _Pragma("unroll") for (int wi_ = 0; wi_ < kNTerms; ++wi_) w[wi_] = a.w[wi_];                                           \
     T w2[kNTerms];                                                                                                         \
     _Pragma("unroll") for (int wi_ = 0; wi_ < kNTerms; ++wi_) w2[wi_] = a.w2[wi_];                                         \
+    T wf[kNTerms];                                                                                                         \
+    _Pragma("unroll") for (int wi_ = 0; wi_ < kNTerms; ++wi_) wf[wi_] = a.wf[wi_];                                         \
     const T *M = a.M, *My = a.My, *tsched = a.tsched;                                                                      \
     const uint8_t *amask = a.amask;                                                                                        \
     const DevTask<T> &tk = a.tasks[t];                                                                                     \
     const BoxRec<T> *boxes = a.boxes + ldu(&tk.box_begin);                                       \
     (void)S; (void)C; (void)Cy; (void)nf; (void)ff; (void)nyf; (void)D; (void)mask; (void)keep_n; (void)use_pref;          \
     (void)tail_start; (void)use_goal_target; (void)goal_tail_n; (void)last_cond; (void)du; (void)inv_du; (void)inv_h2;     \
-    (void)req; (void)pref; (void)appr_tgt; (void)goal_tgt; (void)w; (void)w2; (void)M; (void)My; (void)tsched; (void)amask;          \
+    (void)req; (void)pref; (void)appr_tgt; (void)goal_tgt; (void)w; (void)w2; (void)wf; (void)M; (void)My; (void)tsched; (void)amask;          \
     (void)tk; (void)boxes
     extern __shared__ __align__(16) unsigned char smem_raw[];
     int lane = threadIdx.x & 63;
@@ -691,10 +696,10 @@ __global__ void __launch_bounds__(256, (eval_min_waves<T, GRAD, ROT, WV, NW>()))
             }
         }
         if (FOLD) {   // same order of additions as the cost-only reduction below
-            if (mask & 1u) part += w[0] * t_len;
-            if ((mask & 4u) && S >= 3) part += w[2] * t_ys;
-            if (mask & (1u << 12)) part += w[12] * t_mono;
-            if (mask & (1u << 13)) part += w[13] * t_sched;
+            part = mp_fma(wf[0], t_len, part);
+            part = mp_fma(wf[2], t_ys, part);
+            part = mp_fma(wf[12], t_mono, part);
+            part = mp_fma(wf[13], t_sched, part);
         }
         MP_CAND_SYNC();
         }
@@ -738,7 +743,7 @@ __global__ void __launch_bounds__(256, (eval_min_waves<T, GRAD, ROT, WV, NW>()))
             }
         }
         MP_CAND_SYNC();   // the clearance phase reuses the D1 fields (CC SS D)
-        if (FOLD && (mask & 2u) && S >= 3) part += (w[1] * du) * t_curv;
+        if (FOLD) part = mp_fma(wf[1], t_curv, part);
 
         }
         MP_PHASE(2);  // curvature
@@ -859,13 +864,13 @@ __global__ void __launch_bounds__(256, (eval_min_waves<T, GRAD, ROT, WV, NW>()))
             if (GRAD) RF(k, kGD) = gd;
         }
         if (FOLD) {
-            if (mask & (1u << 3)) part += w[3] * t_safe;
-            if (mask & (1u << 4)) part += w[4] * t_pref;
-            if (mask & (1u << 5)) part += w[5] * t_reb;
-            if (mask & (1u << 6)) part += w[6] * t_gc;
-            if (mask & (1u << 7)) part += w[7] * t_gt;
-            if (mask & (1u << 8)) part += w[8] * t_ac;
-            if (mask & (1u << 9)) part += w[9] * t_acol;
+            part = mp_fma(wf[3], t_safe, part);
+            part = mp_fma(wf[4], t_pref, part);
+            part = mp_fma(wf[5], t_reb, part);
+            part = mp_fma(wf[6], t_gc, part);
+            part = mp_fma(wf[7], t_gt, part);
+            part = mp_fma(wf[8], t_ac, part);
+            part = mp_fma(wf[9], t_acol, part);
         }
 
         }
@@ -882,8 +887,8 @@ __global__ void __launch_bounds__(256, (eval_min_waves<T, GRAD, ROT, WV, NW>()))
             else t_ydev = (mask & (1u << 11)) ? e2 : T(0);
         }
         if (FOLD) {
-            if (mask & (1u << 10)) part = mp_fma(w[10], t_via, part);
-            if (mask & (1u << 11)) part = mp_fma(w[11], t_ydev, part);
+            part = mp_fma(wf[10], t_via, part);
+            part = mp_fma(wf[11], t_ydev, part);
         }
         // goal approach alignment: v = P[S-1] - P[first] (telescoped sum of the tail diffs)
         gn_first = S - goal_tail_n;
@@ -930,7 +935,7 @@ __global__ void __launch_bounds__(256, (eval_min_waves<T, GRAD, ROT, WV, NW>()))
                 jtot += RED[v * 2];
                 mc = mp_min(mc, RED[v * 2 + 1]);
             }
-            if (mask & (1u << 14)) jtot += w[14] * t_gn;
+            jtot = mp_fma(wf[14], t_gn, jtot);
         } else if (!COMPACT && a.terms) {
             term[0] = (mask & 1u) ? wave_sum(t_len) : T(0);
             term[1] = ((mask & 2u) && S >= 3) ? wave_sum(t_curv) * du : T(0);
@@ -955,23 +960,26 @@ __global__ void __launch_bounds__(256, (eval_min_waves<T, GRAD, ROT, WV, NW>()))
             // additions is the order in which the phases produce the sums, so that the five-wave instance, which folds
             // them phase by phase into one register pair, gives the same bits.
             if (!COMPACT) {
-                if (mask & 1u) part += w[0] * t_len;
-                if ((mask & 4u) && S >= 3) part += w[2] * t_ys;
-                if (mask & (1u << 12)) part += w[12] * t_mono;
-                if (mask & (1u << 13)) part += w[13] * t_sched;
-                if ((mask & 2u) && S >= 3) part += (w[1] * du) * t_curv;
-                if (mask & (1u << 3)) part += w[3] * t_safe;
-                if (mask & (1u << 4)) part += w[4] * t_pref;
-                if (mask & (1u << 5)) part += w[5] * t_reb;
-                if (mask & (1u << 6)) part += w[6] * t_gc;
-                if (mask & (1u << 7)) part += w[7] * t_gt;
-                if (mask & (1u << 8)) part += w[8] * t_ac;
-                if (mask & (1u << 9)) part += w[9] * t_acol;
+                // (the same fma per term as the folding instances, which take mask-free weights from the host: a set bit
+                // means wf == w, and wf[1] = w_curv du rounded the same way)
+                if (mask & 1u) part = mp_fma(w[0], t_len, part);
+                if ((mask & 4u) && S >= 3) part = mp_fma(w[2], t_ys, part);
+                if (mask & (1u << 12)) part = mp_fma(w[12], t_mono, part);
+                if (mask & (1u << 13)) part = mp_fma(w[13], t_sched, part);
+                if ((mask & 2u) && S >= 3) part = mp_fma(w[1] * du, t_curv, part);
+                if (mask & (1u << 3)) part = mp_fma(w[3], t_safe, part);
+                if (mask & (1u << 4)) part = mp_fma(w[4], t_pref, part);
+                if (mask & (1u << 5)) part = mp_fma(w[5], t_reb, part);
+                if (mask & (1u << 6)) part = mp_fma(w[6], t_gc, part);
+                if (mask & (1u << 7)) part = mp_fma(w[7], t_gt, part);
+                if (mask & (1u << 8)) part = mp_fma(w[8], t_ac, part);
+                if (mask & (1u << 9)) part = mp_fma(w[9], t_acol, part);
                 if (mask & (1u << 10)) part = mp_fma(w[10], t_via, part);
                 if (mask & (1u << 11)) part = mp_fma(w[11], t_ydev, part);
             }
             jtot = wave_sum(part);
-            if (mask & (1u << 14)) jtot += w[14] * t_gn;
+            if (COMPACT) jtot = mp_fma(wf[14], t_gn, jtot);
+            else if (mask & (1u << 14)) jtot = mp_fma(w[14], t_gn, jtot);
         }
         if constexpr (!WIDE) mc = wave_min(mc);
         if (lane == 0 && wv == 0) {
