@@ -36,6 +36,16 @@ FP32_VALU_PEAK_TFLOPS = 157.3
 HBM_PEAK_GBPS = 8000.0
 
 
+def kernel_sources_hash():
+    """sha256 over the kernel sources, as tools/pmc_summary.py records it beside the counters it summarises."""
+    import hashlib
+
+    h = hashlib.sha256()
+    for rel in ("motion_planning_amd/csrc/mp_kernels.hpp", "motion_planning_amd/csrc/mp_device.hpp", "motion_planning_amd/csrc/mp_api.hip"):
+        h.update((ROOT / rel).read_bytes())
+    return h.hexdigest()
+
+
 def algorithmic_flops(S, Sp, B, C):
     """F = S'*B*f_pair + S*f_samp + 16*S*C, f_pair = 200 (box model + gradient)."""
     return Sp * B * 200 + S * 160 + 16 * S * C
@@ -137,7 +147,7 @@ def workload_sweep(_native, problem, Xh, np_dtype, steps):
     from motion_planning_amd.batch import DeviceBatch
 
     stats = {}
-    sfile = ROOT / "profiles" / "r02_workload_stats.json"
+    sfile = max((ROOT / "profiles").glob("r*_workload_stats.json"), default=ROOT / "profiles" / "none.json")
     if sfile.exists():
         try:
             stats = json.loads(sfile.read_text())
@@ -343,37 +353,54 @@ def main():
     # back to back; with N > 1 the gathers run on RCCL's stream beside them).  `achieved` is EXECUTED FP64 work: the typed
     # VALU instruction counters of gfx950 (SQ_INSTS_VALU_{ADD,MUL,FMA,TRANS}_F64, one count per wave instruction = 64
     # lanes, an FMA = 2 flop) collected by rocprofv3 on this same command (`bench.py --profile-mode`, tools/pmc_passes.sh ->
-    # profiles/r02_pmc/summary.json; the counts per launch are a property of the kernel and the batch, not of the clock),
+    # profiles/r<NN>_pmc[_f32]/summary.json; the counts per launch are a property of the kernel and the batch, not of the clock),
     # divided by the launch duration measured live here.
     bf_flops = algorithmic_flops(N_SAMPLES, N_SAMPLES, N_BOXES, problem.n_ctrl) * N_CAND
     peak = FP64_VALU_PEAK_TFLOPS if args.dtype == "f64" else FP32_VALU_PEAK_TFLOPS
     es = 8 if args.dtype == "f64" else 4
     alg_bytes = (es * problem.dim + es * (problem.dim + 2) + 1) * N_CAND
     traffic, executed, achieved, frac = None, None, None, None
-    pfile = ROOT / "profiles" / "r02_pmc" / "summary.json"
-    if pfile.exists() and args.dtype == "f64":
+    # the newest committed counter set of this dtype whose provenance names the kernel sources of THIS tree (the counts per
+    # launch are a property of the kernels and the batch; a summary taken on other sources would report a stale utilisation,
+    # so it is refused and achieved / frac stay null)
+    pmc_note = "no counter summary under profiles/"
+    for pfile in sorted((ROOT / "profiles").glob("r*_pmc" + ("" if args.dtype == "f64" else "_f32") + "/summary.json"), reverse=True):
         try:
-            g = json.loads(pfile.read_text())["grad"]
+            summ = json.loads(pfile.read_text())
+            g = summ["grad"]
+            prov = summ.get("_provenance", {}).get("kernel_sources_sha256")
+            if prov != kernel_sources_hash():
+                pmc_note = f"{pfile.relative_to(ROOT)} was taken on other kernel sources: refused"
+                continue
             f64_insts = g["SQ_INSTS_VALU_ADD_F64"] + g["SQ_INSTS_VALU_MUL_F64"] + g["SQ_INSTS_VALU_FMA_F64"] + g["SQ_INSTS_VALU_TRANS_F64"]
+            f32_insts = g["SQ_INSTS_VALU_ADD_F32"] + g["SQ_INSTS_VALU_MUL_F32"] + g["SQ_INSTS_VALU_FMA_F32"] + g["SQ_INSTS_VALU_TRANS_F32"]
             f64_flops = 64.0 * (f64_insts + g["SQ_INSTS_VALU_FMA_F64"])          # an FMA counts twice
-            f32_flops = 64.0 * g.get("SQ_INSTS_VALU_FLOPS_FP32", 0.0)
-            achieved = f64_flops / (kern_ms * 1e-3) / 1e12
+            f32_flops = 64.0 * g.get("SQ_INSTS_VALU_FLOPS_FP32", 0.0)            # per-instruction flops, packed operations included
+            own_flops = f64_flops if args.dtype == "f64" else f32_flops
+            achieved = own_flops / (kern_ms * 1e-3) / 1e12
             frac = achieved / peak
             # every wave64 VALU instruction occupies its SIMD's 16-lane ALU for 4 cycles: issue utilisation of the vector
             # ALUs = instructions x 4 cycles / (SIMDs x cycles of the launch)
             cycles = g["GRBM_GUI_ACTIVE"] / 8.0       # the counter sums the 8 XCDs
             executed = {"fp64_flops_per_launch": f64_flops, "fp64_flops_per_eval": f64_flops / N_CAND,
-                        "fp32_flops_per_launch": f32_flops,
+                        "fp32_flops_per_launch": f32_flops, "fp32_flops_per_eval": f32_flops / N_CAND,
                         "valu_insts_per_eval": g["SQ_INSTS_VALU"] / N_CAND, "fp64_insts_per_eval": f64_insts / N_CAND,
+                        "fp32_insts_per_eval": f32_insts / N_CAND,
+                        "fp64_add_mul_fma_per_eval": [g["SQ_INSTS_VALU_ADD_F64"] / N_CAND, g["SQ_INSTS_VALU_MUL_F64"] / N_CAND,
+                                                      g["SQ_INSTS_VALU_FMA_F64"] / N_CAND],
+                        "int_cvt_insts_per_eval": (g["SQ_INSTS_VALU_INT32"] + g["SQ_INSTS_VALU_INT64"] + g["SQ_INSTS_VALU_CVT"]) / N_CAND,
                         "salu_insts_per_eval": g["SQ_INSTS_SALU"] / N_CAND, "lds_insts_per_eval": g["SQ_INSTS_LDS"] / N_CAND,
                         "valu_issue_util": g["SQ_ACTIVE_INST_VALU"] * 4 / (cycles * 1024),
                         "wave_wait_frac": g["SQ_WAIT_ANY"] / g["SQ_WAVE_CYCLES"],
-                        "launch": "eval_kernel<double, 1, true, 0, false, 5, 1> (the five-waves-per-SIMD instance), 65,536 candidates (this command's batch)",
-                        "source": "profiles/r02_pmc/summary.json (rocprofv3 --pmc passes over `bench.py --profile-mode`)"}
+                        "launch": ", ".join(g.get("kernel_names", [])) + ", 65,536 candidates (this command's batch)",
+                        "source": f"{pfile.relative_to(ROOT)} (rocprofv3 --pmc passes over `bench.py --profile-mode`, tools/prof_round.sh)"}
             # HBM bytes per launch: FETCH_SIZE (KiB, x2 on gfx950 per MI355X_MICROARCH.md) + WRITE_SIZE (KiB), separate passes
             traffic = int((2.0 * g["FETCH_SIZE"] + g["WRITE_SIZE"]) * 1024)
-        except Exception:
+            pmc_note = None
+            break
+        except Exception as exc:
             traffic, executed, achieved, frac = None, None, None, None
+            pmc_note = f"{pfile.name}: {exc!r}"
 
     extras = {"timed_region_ms": tail_ms, "gather_own_rows_match": gather_ok, "settle_launches": settle_launches, "settle_note": "untimed launches of the same step before the warm-up steps (clock settling, --settle-s)"}
     if args.profile_mode:
@@ -488,7 +515,7 @@ def main():
                                       + (f", one collective per {G} steps" if distributed else "")},
             "roofline": {"bound": "fp64_valu" if args.dtype == "f64" else "fp32_valu", "achieved": achieved, "peak": peak,
                          "unit": "TFLOP/s", "frac": frac, "traffic": traffic,
-                         "kernel_ms": kern_ms, "executed": executed,
+                         "kernel_ms": kern_ms, "executed": executed, "counters_refused": pmc_note,
                          "algorithmic_bytes_per_eval": alg_bytes // N_CAND,
                          "hbm_algorithmic_GBps": alg_bytes / (kern_ms * 1e-3) / 1e9, "hbm_peak_GBps": HBM_PEAK_GBPS,
                          "bruteforce_flops_per_eval": bf_flops // N_CAND,
@@ -496,7 +523,7 @@ def main():
                          "algorithmic_speedup_vs_bruteforce": bf_flops / (kern_ms * 1e-3) / 1e12 / peak,
                          "note": "bound = FP64 vector ALU (SURVEY 8d: no MFMA-shaped work, 145 B/eval of HBM traffic); peak = "
                                  "datasheet FP64 vector rate.  achieved / frac = EXECUTED FP64 flop/s from the typed VALU counters "
-                                 "(null when profiles/r02_pmc is absent or dtype is not f64); valu_issue_util = share of vector-ALU "
+                                 "(fp32 launches: the FP32 flop counter against the FP32 vector peak; null when no counter summary of these kernel sources is committed, see counters_refused); valu_issue_util = share of vector-ALU "
                                  "issue cycles in use (all instruction types).  The kernel culls ~92 % of the (sample, box) pair "
                                  "evaluations with a conservative bound, so SURVEY's brute-force flop count F is not executed: "
                                  "bruteforce_equiv_tflops = F x evals / time and algorithmic_speedup_vs_bruteforce = that / peak "

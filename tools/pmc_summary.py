@@ -20,4 +20,11 @@ for f in sorted(glob.glob(f"{root}/*/*/*_counter_collection.csv")):
 out = {k: {c: sum(v) / len(v) for c, v in d.items()} for k, d in agg.items()}
 for k in out:
     out[k]["kernel_names"] = sorted(names[k])
+# provenance: the counters are a property of the kernels they were taken on (bench.py refuses a summary of other sources)
+import hashlib, pathlib
+root_dir = pathlib.Path(__file__).resolve().parents[1]
+h = hashlib.sha256()
+for rel in ("motion_planning_amd/csrc/mp_kernels.hpp", "motion_planning_amd/csrc/mp_device.hpp", "motion_planning_amd/csrc/mp_api.hip"):
+    h.update((root_dir / rel).read_bytes())
+out["_provenance"] = {"kernel_sources_sha256": h.hexdigest(), "sources": "mp_kernels.hpp + mp_device.hpp + mp_api.hip"}
 print(json.dumps(out, indent=1))
