@@ -239,9 +239,18 @@ int mp_set_cands_per_task(mp_ctx *ctx, int64_t cands_per_task);
  *   MP_E_ARG with the sizes in mp_last_error.  Point model: MP_E_UNSUPPORTED (its
  *   kernels have no scratch; mp_eval never allocates for it).
  *   All calls on one GPU share that GPU's array, which keeps the last call's contents
- *   (nothing in it needs clearing: every entry a call reads it has written before):
- *   calls that overlap on one GPU — two contexts, two streams — race on it; serialise
- *   them, or use mp_eval for all but one. */
+ *   (nothing in it needs clearing: every entry a call reads it has written before).
+ *   The library orders them: a call that comes on another stream than the previous one
+ *   first waits on the device (hipStreamWaitEvent on an event recorded behind that call:
+ *   no allocation, no host wait), so two contexts or two streams do not race on the
+ *   tables.  The exception is a call made while its stream is being CAPTURED into a
+ *   graph: it takes no part in that ordering (events of uncaptured work cannot enter a
+ *   graph), and replays of the captured call that overlap other users of the array on
+ *   the same GPU race on it; order them yourself.  Results are bit-identical to
+ *   mp_eval's for every box-model launch whose mp_eval also runs the split kernels,
+ *   and differ from a fused mp_eval launch only where the wide instance adds its sums
+ *   in another order (S > 176: <= 1e-12 relative in cost and gradient; clearances and
+ *   flags always the same bits). */
 #define MP_NOALLOC_SCRATCH_BYTES (32u << 20)
 int mp_eval_noalloc(mp_ctx *ctx, int64_t n, const void *X, const int32_t *task_of, void *cost,
                     void *grad, void *min_clear, uint8_t *flags);

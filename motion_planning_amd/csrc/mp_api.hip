@@ -11,6 +11,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <unordered_map>
 #include <vector>
 
@@ -30,7 +31,18 @@ static __device__ __align__(256) unsigned char scratch[MP_NOALLOC_SCRATCH_BYTES]
 #endif
 namespace {
 
-void *g_scratch_ptr[64] = {nullptr};   // [device] address of that GPU's copy of `scratch` (each GPU has its own)
+std::atomic<void *> g_scratch_ptr[64];   // [device] address of that GPU's copy of `scratch` (each GPU has its own)
+// Every context of a GPU shares that GPU's array.  Calls on ONE stream are ordered by the stream; a call that comes on
+// another stream first waits (hipStreamWaitEvent: no allocation) for the event recorded behind the previous call, so two
+// contexts or streams cannot race on the tables.  Calls made while a stream is being captured cannot take part (an event of
+// uncaptured work must not enter a graph): replays of a captured call are ordered by the caller, as documented in mp_api.h.
+struct ScratchOrder {
+    std::mutex m;
+    hipEvent_t done = nullptr;     // created by the first mp_create on the device
+    hipStream_t last = nullptr;
+    bool recorded = false;
+};
+ScratchOrder g_scratch_order[64];
 
 thread_local char g_create_err[512] = "";
 
@@ -496,19 +508,17 @@ int launch_eval_p(mp_ctx *ctx, const mp::EvalArgs<T> &args, int wpb, int blocks,
         if (args.wide == 3) kern = mp::eval_kernel<T, MODEL, GRAD, ROT, PRE, 0, 3>;
     }
     if (lds_bytes > 65536) {
-        // the opt-in for > 64 KB of dynamic LDS is per kernel variant and device: set once, raise when a larger slice comes
-        static std::atomic<int> granted[64];
-        static std::atomic<const void *> granted_for[64];   // the instance (standard / compact) the grant was made for
-        std::atomic<int> &g = granted[ctx->device & 63];
-        std::atomic<const void *> &gf = granted_for[ctx->device & 63];
-        if (gf.load(std::memory_order_relaxed) != reinterpret_cast<const void *>(kern)) {
-            g.store(0, std::memory_order_relaxed);
-            gf.store(reinterpret_cast<const void *>(kern), std::memory_order_relaxed);
-        }
-        if ((int)lds_bytes > g.load(std::memory_order_relaxed)) {
-            HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                             (int)lds_bytes));
-            g.store((int)lds_bytes, std::memory_order_relaxed);
+        // the opt-in for > 64 KB of dynamic LDS is per kernel variant and device: remembered per (device, kernel), raised when a
+        // larger slice comes.  Contexts on several host threads share the table (one mutex; the path is taken by launches
+        // of more than ~540 fp64 samples only).
+        static std::mutex grant_mutex;
+        static std::unordered_map<const void *, int> granted[64];
+        const void *key = reinterpret_cast<const void *>(kern);
+        std::lock_guard<std::mutex> lock(grant_mutex);
+        int &g = granted[ctx->device & 63][key];
+        if ((int)lds_bytes > g) {
+            HIP_TRY(ctx, hipFuncSetAttribute(key, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+            g = (int)lds_bytes;
         }
     }
     hipLaunchKernelGGL(kern, dim3(blocks), dim3(64 * wpb), lds_bytes, ctx->stream, args);
@@ -881,11 +891,17 @@ int mp_create(int device_id, int dtype, mp_ctx **out)
     ctx->stream = ctx->own_stream;
     if ((e = hipEventCreate(&ctx->ev0)) != hipSuccess) return bail("hipEventCreate", e);
     if ((e = hipEventCreate(&ctx->ev1)) != hipSuccess) return bail("hipEventCreate", e);
-    if (device_id < 64 && !g_scratch_ptr[device_id]) {
-        // this GPU's copy of the static scratch array of mp_eval_noalloc (device_id is current here)
-        void *ptr = nullptr;
-        if ((e = hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch))) != hipSuccess) return bail("hipGetSymbolAddress(scratch)", e);
-        g_scratch_ptr[device_id] = ptr;
+    if (device_id < 64) {
+        // this GPU's copy of the static scratch array of mp_eval_noalloc (device_id is current here); contexts may be created
+        // on several host threads at once
+        std::lock_guard<std::mutex> lock(g_scratch_order[device_id].m);
+        if (!g_scratch_ptr[device_id].load(std::memory_order_acquire)) {
+            void *ptr = nullptr;
+            if ((e = hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch))) != hipSuccess) return bail("hipGetSymbolAddress(scratch)", e);
+            if ((e = hipEventCreateWithFlags(&g_scratch_order[device_id].done, hipEventDisableTiming)) != hipSuccess)
+                return bail("hipEventCreate(scratch order)", e);
+            g_scratch_ptr[device_id].store(ptr, std::memory_order_release);
+        }
     }
     *out = ctx;
     return MP_OK;
@@ -1217,7 +1233,7 @@ int mp_eval_noalloc(mp_ctx *ctx, int64_t n, const void *X, const int32_t *task_o
     }
     if (!task_of && ctx->n_tasks == 1 && ctx->cands_per_task > 0 && n > ctx->cands_per_task)
         return fail(ctx, MP_E_ARG, "mp_eval_noalloc: n exceeds n_tasks * cands_per_task");
-    void *ptr = ctx->device < 64 ? g_scratch_ptr[ctx->device] : nullptr;
+    void *ptr = ctx->device < 64 ? g_scratch_ptr[ctx->device].load(std::memory_order_acquire) : nullptr;
     if (!ptr) return fail(ctx, MP_E_STATE, "mp_eval_noalloc: no scratch address for device %d", ctx->device);
     const size_t es = esize(ctx), samples = (size_t)n * (size_t)c.n_safe;
     const size_t need = noalloc_arg_offset(samples * es) + samples * sizeof(int);
@@ -1227,9 +1243,23 @@ int mp_eval_noalloc(mp_ctx *ctx, int64_t n, const void *X, const int32_t *task_o
                     (size_t)MP_NOALLOC_SCRATCH_BYTES);
     // Nothing in the tables has to start at zero: clearance_kernel writes every (candidate, sample) entry that
     // eval_kernel reads afterwards on the same stream; entries of the previous call beyond n x S' are never read.
-    return ctx->dtype == MP_F64
-               ? launch_eval<double>(ctx, n, X, task_of, cost, nullptr, grad, min_clear, flags, nullptr, 0, nullptr, nullptr, ptr)
-               : launch_eval<float>(ctx, n, X, task_of, cost, nullptr, grad, min_clear, flags, nullptr, 0, nullptr, nullptr, ptr);
+    ScratchOrder &ord = g_scratch_order[ctx->device];
+    std::lock_guard<std::mutex> lock(ord.m);
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (ctx->stream == nullptr || hipStreamIsCapturing(ctx->stream, &cap) != hipSuccess) { (void)hipGetLastError(); cap = hipStreamCaptureStatusNone; }
+    const bool capturing = cap != hipStreamCaptureStatusNone;
+    if (!capturing && ord.recorded && ord.last != ctx->stream)
+        HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ord.done, 0));   // the previous user of this GPU's tables, on another stream
+    rc = ctx->dtype == MP_F64
+             ? launch_eval<double>(ctx, n, X, task_of, cost, nullptr, grad, min_clear, flags, nullptr, 0, nullptr, nullptr, ptr)
+             : launch_eval<float>(ctx, n, X, task_of, cost, nullptr, grad, min_clear, flags, nullptr, 0, nullptr, nullptr, ptr);
+    if (rc) return rc;
+    if (!capturing) {
+        HIP_TRY(ctx, hipEventRecord(ord.done, ctx->stream));
+        ord.last = ctx->stream;
+        ord.recorded = true;
+    }
+    return MP_OK;
 }
 
 static int sdf_common(mp_ctx *ctx, int64_t n, int32_t box_begin, int32_t box_count, int mem, const char *who)

@@ -37,6 +37,7 @@ class Scene:
         self._device = device
         self._ctx = None
         self._ctx_key = None
+        self._ctx_frame = None    # second context: tilted-mover queries (the scene re-expressed in the mover frame)
 
     # ---- ids -------------------------------------------------------------------------
     def _claim_id(self, wanted: Optional[str]) -> str:
@@ -72,13 +73,17 @@ class Scene:
 
     # ---- distance queries (native) -------------------------------------------------------
     def _native(self, ignore_ids: Optional[Sequence[str]] = None):
+        """The context with this scene resident.  The key is the CONTENT of the box table (size, position, quaternion of every
+        block that is not ignored), so a block mutated in place is uploaded again; building the table is O(blocks) host work,
+        far below the cost of a query."""
         from . import _native
 
-        key = (len(self.blocks), tuple(sorted(set(ignore_ids or []))))
+        rows = np.ascontiguousarray(scene_to_boxes(self, ignore_ids))
+        key = (rows.shape, rows.tobytes())
         if self._ctx is None:
             self._ctx = _native.Context(self._device, np.float64)
         if self._ctx_key != key:
-            self._ctx.set_scene(scene_to_boxes(self, ignore_ids))
+            self._ctx.set_scene(rows)
             self._ctx_key = key
         return self._ctx
 
@@ -113,10 +118,12 @@ class Scene:
         rows = as_boxes10(scene_to_boxes(self, ignore_ids))
         if rows.shape[0] == 0:
             return float("inf")
-        ctx = self._native(ignore_ids)
-        ctx.set_scene(boxes_in_frame(rows, position, quat))
-        self._ctx_key = None   # the resident scene is now the transformed one
-        return float(ctx.box_sdf(size, np.zeros((1, 3)), np.zeros(1))[0])
+        from . import _native
+
+        if self._ctx_frame is None:      # a second context: the resident scene of the yaw-only queries stays where it is
+            self._ctx_frame = _native.Context(self._device, np.float64)
+        self._ctx_frame.set_scene(boxes_in_frame(rows, position, quat))
+        return float(self._ctx_frame.box_sdf(size, np.zeros((1, 3)), np.zeros(1))[0])
 
     def sample_sdf_grid(self, bounds, dims):
         """Point SDF on a regular grid (geom/scene.py:157-170), one batched query."""

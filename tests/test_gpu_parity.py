@@ -332,6 +332,16 @@ def test_scene_class_queries(oracle_lib):
     (xs, ys, zs), grid = s.sample_sdf_grid(((-1, 1), (-1, 1), (0, 2)), (5, 4, 3))
     assert grid.shape == (5, 4, 3) and grid[2, 1, 0] <= 0
     assert Scene().signed_distance_block((1, 1, 1), (0, 0, 0)) == np.inf
+    # a block mutated in place is seen by the next query (the device copy is keyed by the scene's content, not its length)
+    before = s.signed_distance((0.0, 0.0, 2.5))
+    s.get_block("wall").position = (0.0, 0.0, 1.0)
+    moved = np.array([[*b.position, *(0.5 * np.asarray(b.size))] for b in s.blocks], dtype=float)
+    after = s.signed_distance((0.0, 0.0, 2.5))
+    assert after == oracle_lib.point_sdf(moved, np.array([[0.0, 0.0, 2.5]]))[0] and after != before
+    # a tilted-mover query (second context) leaves the resident scene of the yaw-only queries alone
+    q = np.array([0.3, 0.1, 0.2, 0.9]); q /= np.linalg.norm(q)
+    s.signed_distance_block((0.6, 0.9, 0.6), (0.3, 0.2, 1.4), tuple(q))
+    assert s.signed_distance((0.0, 0.0, 2.5)) == after
 
 
 def test_full_size_properties(native):

@@ -122,6 +122,49 @@ def test_noalloc_with_tasks_rotations_and_the_wide_instance(shape):
         ctx.close()
 
 
+def test_noalloc_calls_from_two_contexts_do_not_race():
+    """Two contexts with streams of their own on one GPU (different problems, different batch sizes) issue their
+    mp_eval_noalloc calls back to back without any host synchronisation in between: the library orders the users of the
+    GPU's one scratch array on the device, so every call still gives mp_eval's bits (round-2 advisor finding: overlapping
+    calls silently corrupted each other's tables)."""
+    import torch
+
+    from motion_planning_amd import _native as native
+    from motion_planning_amd.synthetic import synthetic_candidates, synthetic_problem
+
+    vp = C.c_void_p
+    probs = [synthetic_problem(native.build_basis, 300, 256, seed=1, size_range=(0.05, 0.3)),
+             synthetic_problem(native.build_basis, 50, 64, seed=0)]
+    sizes = [3000, 20000]
+    ctxs, Xs, refs, gots = [], [], [], []
+    for p, n in zip(probs, sizes):
+        ctx = native.Context(0)
+        ctx.set_problem(p)
+        X = torch.from_numpy(synthetic_candidates(p, n, seed=21)).cuda()
+        ref = {"cost": torch.empty(n, dtype=torch.float64, device="cuda"), "grad": torch.empty(n, p.dim, dtype=torch.float64, device="cuda"),
+               "flags": torch.empty(n, dtype=torch.uint8, device="cuda")}
+        rc = ctx.lib.mp_eval(ctx._h, n, vp(X.data_ptr()), None, vp(ref["cost"].data_ptr()), None, vp(ref["grad"].data_ptr()), None,
+                             vp(ref["flags"].data_ptr()), None, abi.MP_MEM_DEVICE)
+        assert rc == 0, ctx.lib.mp_last_error(ctx._h)
+        ctx.synchronize()
+        ctxs.append(ctx); Xs.append(X); refs.append(ref)
+        gots.append([{k: torch.zeros_like(v) for k, v in ref.items()} for _ in range(6)])
+    for rep in range(6):          # A B A B ... on two streams, nothing waits on the host
+        for ctx, X, got, n in zip(ctxs, Xs, gots, sizes):
+            g = got[rep]
+            rc = ctx.lib.mp_eval_noalloc(ctx._h, n, vp(X.data_ptr()), None, vp(g["cost"].data_ptr()), vp(g["grad"].data_ptr()), None,
+                                         vp(g["flags"].data_ptr()))
+            assert rc == 0, ctx.lib.mp_last_error(ctx._h)
+    for ctx in ctxs:
+        ctx.synchronize()
+    for ref, got in zip(refs, gots):
+        for g in got:
+            for k in ref:
+                assert torch.equal(g[k], ref[k]), k
+    for ctx in ctxs:
+        ctx.close()
+
+
 def test_noalloc_limits_and_errors():
     import torch
 
