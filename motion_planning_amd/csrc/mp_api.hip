@@ -85,6 +85,9 @@ struct mp_ctx {
     void *h_pin = nullptr;        // pinned, device-visible host staging for small host-buffer calls (zero copy)
     size_t h_pin_cap = 0;
     DevBuf s_pre_d, s_pre_arg;    // split mode: clearance profile + deciding box of every (candidate, sample)
+    DevBuf d_seed, d_seed_d;      // CEM: deciding boxes [n_inst x n_safe] of the instances' mean trajectories, and their clearances (cem_solve)
+    int seed_mode = 1;            // 0: no seeds (MP_SEEDS=0, tuning aid / A-B)
+    int defer_mode = 1;           // 0: every chunk of a trajectory drains its own queue (MP_DEFER=0, tuning aid / A-B)
     int max_task_boxes = 0;
     int idx_identity = 0;         // idx_safe is 0, 1, 2, ...
     int split_mode = -1;          // -1 automatic, 0 never, 1 always (MP_SPLIT_CLEARANCE, tuning aid)
@@ -544,7 +547,7 @@ int launch_eval_k(mp_ctx *ctx, const mp::EvalArgs<T> &args, int wpb, int blocks,
 template <typename T>
 int launch_eval(mp_ctx *ctx, long long n, const void *X, const int32_t *task_of, void *cost, void *terms, void *grad,
                 void *minc, uint8_t *flags, void *dist, int group_size = 0, const int *group_task = nullptr,
-                const uint8_t *group_done = nullptr, void *ext_scratch = nullptr)
+                const uint8_t *group_done = nullptr, void *ext_scratch = nullptr, const int *seeds = nullptr, bool seed_pass = false)
 {
     const mp_config &c = ctx->cfg;
     mp::EvalArgs<T> a{};
@@ -577,6 +580,26 @@ int launch_eval(mp_ctx *ctx, long long n, const void *X, const int32_t *task_of,
     a.group_size = group_size; a.group_task = group_task; a.group_done = group_done;
     a.cost = (T *)cost; a.terms = (T *)terms; a.grad = (T *)grad; a.minc = (T *)minc; a.dist = (T *)dist;
     a.flags = flags;
+    a.seed = (group_size > 0 && grad == nullptr && !seed_pass) ? seeds : nullptr;
+    // exact passes shared between the chunks of a trajectory (clearance_chunk): a queue entry then holds the trajectory's sample
+    // index; 16-bit entries (compact instances) have 7 + 9 bits for it and the box, 32-bit entries 10 + 22
+    a.defer = 0;   // 1: entries of either width have the room, 2: 32-bit entries only
+    if (ctx->defer_mode && c.n_safe > 64 && c.n_safe <= 1024 && ctx->max_task_boxes < (1 << 22))
+        a.defer = (c.n_safe <= 128 && ctx->max_task_boxes < 512) ? 1 : 2;
+    if (seed_pass) {
+        // the mean trajectory of every CEM instance through clearance_kernel: its table of deciding boxes is the seed table of
+        // the instance's next population (one row per instance: group_size == 1 here)
+        a.pre_d = (T *)ctx->d_seed_d.p;
+        a.pre_arg = (int *)ctx->d_seed.p;
+        const long long units = n * ((c.n_safe + 63) / 64);
+        const int cblocks = (int)std::min<long long>((units + 3) / 4, (long long)ctx->num_cu * 128);
+        const size_t clds = (size_t)4 * mp::clearance_lds_bytes_per_wave((int)sizeof(T));
+        if (ctx->has_rot == 2) hipLaunchKernelGGL((mp::clearance_kernel<T, 2>), dim3(cblocks), dim3(256), clds, ctx->stream, a);
+        else if (ctx->has_rot) hipLaunchKernelGGL((mp::clearance_kernel<T, 1>), dim3(cblocks), dim3(256), clds, ctx->stream, a);
+        else hipLaunchKernelGGL((mp::clearance_kernel<T, 0>), dim3(cblocks), dim3(256), clds, ctx->stream, a);
+        HIP_TRY(ctx, hipGetLastError());
+        return MP_OK;
+    }
 
     // Five-wave instance of the fp64 gradient kernel (mp_kernels.hpp, WV = 5): fused axis-aligned box scenes with one
     // 64-sample chunk, < 1024 boxes per task and a waypoint table of <= 256 bytes, when five four-wave blocks of its compact
@@ -738,6 +761,18 @@ int cem_solve(mp_ctx *ctx, long long n_inst, const int32_t *d_task, const T *d_x
     if ((rc = reserve(ctx, ctx->c_done, (size_t)n_inst))) return rc;
     if ((rc = reserve(ctx, ctx->c_nit, (size_t)n_inst * sizeof(int)))) return rc;
     if ((rc = reserve(ctx, ctx->c_active, 256))) return rc;
+    // seeds of the clearance bound (mp_kernels.hpp, clearance_chunk): the deciding boxes of every instance's mean trajectory,
+    // refreshed after every update of the mean (1 / population of an evaluation's work)
+    const bool seeded = ctx->seed_mode && c.model == MP_MODEL_BOX && ctx->max_task_boxes >= 2;
+    if (seeded) {
+        if ((rc = reserve(ctx, ctx->d_seed, (size_t)n_inst * c.n_safe * sizeof(int)))) return rc;
+        if ((rc = reserve(ctx, ctx->d_seed_d, (size_t)n_inst * c.n_safe * sizeof(T)))) return rc;
+    }
+    auto seed_pass = [&]() -> int {
+        if (!seeded) return MP_OK;
+        return launch_eval<T>(ctx, n_inst, ctx->c_mu.p, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 1, d_task,
+                              (const uint8_t *)ctx->c_done.p, nullptr, nullptr, true);
+    };
     HIP_TRY(ctx, hipMemsetAsync(ctx->c_active.p, 0, 256, ctx->stream));   // [0] running count, [1] generation counter
     mp::CemState<T> st{(T *)ctx->c_mu.p, (T *)ctx->c_sigma.p, (T *)ctx->c_bestx.p, (T *)ctx->c_bestval.p,
                        (T *)ctx->c_prev.p, (T *)ctx->c_bminc.p, (uint8_t *)ctx->c_bflags.p, (uint8_t *)ctx->c_done.p,
@@ -746,6 +781,7 @@ int cem_solve(mp_ctx *ctx, long long n_inst, const int32_t *d_task, const T *d_x
     hipLaunchKernelGGL(mp::cem_init_kernel<T>, dim3(std::max(eb, 1)), dim3(256), 0, ctx->stream, n_inst, D, st, d_x0, d_s0,
                        (T)o.min_sigma);
     HIP_TRY(ctx, hipGetLastError());
+    if ((rc = seed_pass())) return rc;   // first population: seeds from x0
     const int sb = (int)std::min<long long>(((long long)np_ * D + 255) / 256, (long long)ctx->num_cu * 16);
     const int wpb = 4;
     const int ub = (int)std::min<long long>((n_inst + wpb - 1) / wpb, (long long)ctx->num_cu * 16);
@@ -756,13 +792,15 @@ int cem_solve(mp_ctx *ctx, long long n_inst, const int32_t *d_task, const T *d_x
                            (unsigned long long)o.seed, (unsigned long long)o.instance_base, (T *)ctx->c_X.p);
         if (hipGetLastError() != hipSuccess) return MP_E_HIP;
         int r = launch_eval<T>(ctx, (long long)np_, ctx->c_X.p, nullptr, ctx->c_vals.p, nullptr, nullptr, ctx->c_minc.p,
-                               (uint8_t *)ctx->c_flags.p, nullptr, pop, d_task, (const uint8_t *)ctx->c_done.p);
+                               (uint8_t *)ctx->c_flags.p, nullptr, pop, d_task, (const uint8_t *)ctx->c_done.p, nullptr,
+                               seeded ? (const int *)ctx->d_seed.p : nullptr);
         if (r) return r;
         hipLaunchKernelGGL(mp::cem_tick_kernel<T>, dim3(1), dim3(64), 0, ctx->stream, st);
         hipLaunchKernelGGL(mp::cem_update_kernel<T>, dim3(ub), dim3(64 * wpb), ulds, ctx->stream, n_inst, pop, D, n_elite,
                            (T)o.alpha, (T)o.min_sigma, (T)o.tol, st, (const T *)ctx->c_X.p, (const T *)ctx->c_vals.p,
                            (const T *)ctx->c_minc.p, (const uint8_t *)ctx->c_flags.p);
-        return hipGetLastError() == hipSuccess ? MP_OK : MP_E_HIP;
+        if (hipGetLastError() != hipSuccess) return MP_E_HIP;
+        return seed_pass();
     };
     auto still_running = [&](int &active) -> int {
         HIP_TRY(ctx, hipMemcpyAsync(&active, ctx->c_active.p, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
@@ -872,6 +910,8 @@ int mp_create(int device_id, int dtype, mp_ctx **out)
     mp_ctx *ctx = new mp_ctx();
     ctx->device = device_id;
     if (const char *sm = std::getenv("MP_SPLIT_CLEARANCE")) ctx->split_mode = std::atoi(sm) != 0 ? 1 : 0;
+    if (const char *sm = std::getenv("MP_SEEDS")) ctx->seed_mode = std::atoi(sm) != 0 ? 1 : 0;
+    if (const char *sm = std::getenv("MP_DEFER")) ctx->defer_mode = std::atoi(sm) != 0 ? 1 : 0;
     if (const char *wm = std::getenv("MP_WIDE")) ctx->wide_mode = std::atoi(wm) != 0 ? -1 : 0;
     if (const char *ws = std::getenv("MP_WIDE_MIN_S")) ctx->wide_min_s = std::atoi(ws);
     if (const char *fw = std::getenv("MP_FIVE_WAVES")) ctx->five_wave_mode = std::atoi(fw) != 0 ? -1 : 0;
@@ -915,7 +955,7 @@ int mp_destroy(mp_ctx *ctx)
     hipStreamSynchronize(ctx->stream);
     DevBuf *bufs[] = {&ctx->boxes, &ctx->boxes32, &ctx->pairs32, &ctx->groups, &ctx->d_idx, &ctx->d_inv, &ctx->d_mask, &ctx->d_M, &ctx->d_My, &ctx->d_tsched, &ctx->d_tasks,
                       &ctx->s_X, &ctx->s_taskof, &ctx->s_cost, &ctx->s_terms, &ctx->s_grad, &ctx->s_minc,
-                      &ctx->s_flags, &ctx->s_dist, &ctx->s_aux0, &ctx->s_aux1, &ctx->s_pre_d, &ctx->s_pre_arg, &ctx->tilt, &ctx->c_X, &ctx->c_vals, &ctx->c_minc,
+                      &ctx->s_flags, &ctx->s_dist, &ctx->s_aux0, &ctx->s_aux1, &ctx->s_pre_d, &ctx->s_pre_arg, &ctx->d_seed, &ctx->d_seed_d, &ctx->tilt, &ctx->c_X, &ctx->c_vals, &ctx->c_minc,
                       &ctx->c_flags, &ctx->c_mu, &ctx->c_sigma, &ctx->c_bestx, &ctx->c_bestval, &ctx->c_prev, &ctx->c_bminc,
                       &ctx->c_bflags, &ctx->c_done, &ctx->c_nit, &ctx->c_active, &ctx->c_task, &ctx->c_x0, &ctx->c_s0,
                       &ctx->c_noise};

@@ -6,6 +6,7 @@
 // differences, tail windows) go through a per-wave LDS slice; per-trajectory sums use
 // wavefront shuffles.  No MFMA: the spline product is a C<=16 term contraction per sample.
 #pragma once
+#include <type_traits>
 #include "mp_device.hpp"
 
 namespace mp {
@@ -110,6 +111,10 @@ template <typename T> struct EvalArgs {
     // split mode (large S): clearance_kernel fills these [n x Sp] tables, eval_kernel reads them
     T *pre_d;      // clearance of every collision sample
     int *pre_arg;  // its deciding box, relative to the task's range (-1: none)
+    int defer;         // fused box-model launches with several 64-sample chunks: queue entries carry the trajectory's sample index
+                       // (host: n_safe and the tasks' box counts fit the entry; clearance_chunk)
+    const int *seed;   // cost-only launches of candidate groups (CEM populations): [n_groups x Sp] deciding box of every collision
+                       // sample on the group's mean trajectory (nullptr: no seeds; set only together with group_size > 0)
 };
 
 // collision sample k -> spline sample (identity unless the path is subsampled for collision checks)
@@ -257,11 +262,21 @@ constexpr int kChunkRec = 7;   // record of clearance_kernel: P0 P1 P2 YW CC SS 
 // consecutive slots (1: an array; NREC: the keys are a field of the fp64 records).
 // AS: the same for the deciding-box words (in ints).  Q16: work-queue entries are 16 bits (lane << 10 | box; every task < 1024 boxes).
 // ARGS: keep the deciding box of every sample (the gradient needs it; cost-only launches skip the second atomic and its barriers).
-template <typename T, int ROT, bool LOCAL, bool SEED, int NREC, int KS = 1, int AS = 1, bool Q16 = false, bool ARGS = true, typename AT>
+template <typename T, int ROT, bool LOCAL, bool SEED, int NREC, int KS = 1, int AS = 1, bool Q16 = false, bool ARGS = true, bool SEEDED = false, typename AT>
 __device__ __forceinline__ void clearance_chunk(const AT &a, const BoxRec<T> *boxes, const BoxRec32 *boxes32, const BoxPair32 *pairs,
                                                 const BoxRec32 *groups, int ngroups, int n_wide, int lane, int k0, int Sp, T *REC,
-                                                unsigned long long *MINKEY, int *ARG, unsigned int *QUEUE)
+                                                unsigned long long *MINKEY, int *ARG, unsigned int *QUEUE, const int *seed_row,
+                                                int &qcarry, bool defer, bool keep_tail)
 {
+    // Slots: a LOCAL caller (clearance_kernel) hands in the 64 slots of this chunk, a fused caller the slots of the whole
+    // trajectory; `own` is this lane's.  Queue entries are (sample << kshift | box); with `defer` (the same for every chunk
+    // of a trajectory) the sample is the trajectory's collision sample index, so that entries of different chunks can share
+    // an exact pass (`keep_tail`, below), without it the lane within the chunk.
+    const int q0 = LOCAL ? 0 : k0;
+    const int own = q0 + lane;
+    const int kbase = defer ? 0 : q0;
+    const int kshift = Q16 ? (defer ? 9 : 10) : (defer ? 22 : 24);
+    const unsigned int kmask = (1u << kshift) - 1u;
     const float ax32 = (float)a.ax, ay32 = (float)a.ay, az32 = (float)a.az;
     // this lane's own collision sample
     const bool valid = k0 + lane < Sp;
@@ -273,8 +288,8 @@ __device__ __forceinline__ void clearance_chunk(const AT &a, const BoxRec<T> *bo
         T c, sn;
         yaw_rot(rs[kYW], a.trig, c, sn);
         rk[kCC] = c; rk[kSS] = sn;
-        MINKEY[lane * KS] = key_init<T>();
-        if (ARGS) ARG[lane * AS] = -1;
+        MINKEY[own * KS] = key_init<T>();
+        if (ARGS) ARG[own * AS] = -1;
         px32 = (float)rs[kP0]; py32 = (float)rs[kP1]; pz32 = (float)rs[kP2];
         const float c32 = __builtin_fabsf((float)c), s32 = __builtin_fabsf((float)sn);
         slack = 2e-6f * (__builtin_fabsf(px32) + __builtin_fabsf(py32) + __builtin_fabsf(pz32) +
@@ -295,14 +310,13 @@ __device__ __forceinline__ void clearance_chunk(const AT &a, const BoxRec<T> *bo
     // running upper bound of the lane's squared clearance; -1 on lanes without a sample, so that `lb2 <= U32`
     // alone (one v_cmp, whose result is the ballot) says whether the lane needs a pair
     float U32 = valid ? __builtin_huge_valf() : -1.0f;
-    const unsigned int lane10 = (unsigned int)lane << 10, lane24 = (unsigned int)lane << 24;
-    (void)lane10; (void)lane24;
+    const unsigned int lane_hi = (unsigned int)(defer ? own : lane) << kshift;
     // Work queue: a LINEAR array of up to 128 entries, filled from the front.  An exact pass takes entries 0 .. 63 and moves
     // what lies behind them (fewer than 64 entries) to the front, so a push needs no ring arithmetic: its slot is
     // qcount + (needing lanes below this one), which v_mbcnt delivers with qcount as its start value.
-    int qcount = 0;  // wave-uniform
+    int qcount = qcarry;  // wave-uniform; entries a previous chunk of the trajectory left behind (defer)
     MP_STAT_ADD(0, 1);
-    if (SEED && ngroups > 1) {
+    if (SEED && ngroups > 1 && !(SEEDED && seed_row)) {
         // Seed of the upper bound: the mover's centre lies in the mover and a box's centre in the box, so the scene
         // value is at most the distance from this sample to the centre of any box.  One representative box per
         // group (record 2g+1), coordinates inflated by the slack, keeps the first groups of the sweep from
@@ -330,18 +344,12 @@ __device__ __forceinline__ void clearance_chunk(const AT &a, const BoxRec<T> *bo
         unsigned int moved = 0;
         if (lane < rest) moved = Q16 ? (unsigned int)reinterpret_cast<const unsigned short *>(QUEUE)[64 + lane] : QUEUE[64 + lane];
         if (act) {
-            if (Q16) {
-                const unsigned int e = reinterpret_cast<const unsigned short *>(QUEUE)[lane];
-                kk = (int)(e >> 10);
-                bb = (int)(e & 0x3ffu);
-            } else {
-                const unsigned int e = QUEUE[lane];
-                kk = (int)(e >> 24);
-                bb = (int)(e & 0xffffffu);
-            }
-            const int ss = LOCAL ? kk : sample_of(a, k0 + kk);
+            const unsigned int e = Q16 ? (unsigned int)reinterpret_cast<const unsigned short *>(QUEUE)[lane] : QUEUE[lane];
+            kk = kbase + (int)(e >> kshift);
+            bb = (int)(e & kmask);
+            const int ss = LOCAL ? kk : sample_of(a, kk);
             const BoxRec<T> bx = boxes[bb];
-            const T *rs = REC + ss * NREC, *rk = REC + (LOCAL ? kk : k0 + kk) * NREC;
+            const T *rs = REC + ss * NREC, *rk = REC + kk * NREC;
             const T qz = rs[kP2];
             T qx = rs[kP0], qy = rs[kP1], qc = rk[kCC], qs = rk[kSS], bcx = bx.cx, bcy = bx.cy;
             if (ROT == 2 && box_is_tilted(bx)) {   // general rotation: the (large, rare) exact OBB routine
@@ -392,7 +400,7 @@ __device__ __forceinline__ void clearance_chunk(const AT &a, const BoxRec<T> *bo
             wave_lds_sync();
         }
         if (valid) {
-            const unsigned long long kcur = MINKEY[lane * KS];
+            const unsigned long long kcur = MINKEY[own * KS];
             U32 = __builtin_fminf(U32, (float)key_to_sep2<T>(kcur) * (1.0f + 4e-6f));   // never above the seed
             if (!(kcur & kSepBit)) {
                 // penetrating: shrink by the depth, rounded down (4e-6 relative covers the conversion to fp32)
@@ -403,11 +411,27 @@ __device__ __forceinline__ void clearance_chunk(const AT &a, const BoxRec<T> *bo
         }
     };
 
+    auto push = [&](bool need, int idx) {
+        const unsigned long long m = __builtin_amdgcn_ballot_w64(need);
+        if (m) {
+            if (need) {
+                const int pos = __builtin_amdgcn_mbcnt_hi((unsigned int)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)m, (unsigned int)qcount));
+                if (Q16) reinterpret_cast<unsigned short *>(QUEUE)[pos] = (unsigned short)(lane_hi | (unsigned int)idx);
+                else QUEUE[pos] = lane_hi | (unsigned int)idx;
+            }
+            qcount += __builtin_popcountll(m);
+            if (qcount >= 64) {
+                drain(64, qcount - 64);
+                qcount -= 64;
+            }
+        }
+    };
+
     // Wide box first (a table, a floor; chosen on the host, axis-aligned scenes only, record 0 of the table).  Where
     // the mover's centre lies over its footprint the two footprints overlap for certain (every 2-D SAT gap is at most
     // minus the mover's smaller half extent), so with a positive z gap the pair value is gz^2, computed exactly as
     // pair_key would, and the lane settles the pair on its own sample slot; the other lanes queue it as usual
-    // (at most 64 entries: no drain needed here).
+    // through the queue.
     if (!ROT && n_wide > 0) {
         const BoxRec32 bx = load_box32_uniform(boxes32, 0);
         const int bi = __float_as_int(bx.pad0);
@@ -418,23 +442,38 @@ __device__ __forceinline__ void clearance_chunk(const AT &a, const BoxRec<T> *bo
             const T *rw = REC + sw * NREC;
             const T gz = mp_abs(rw[kP2] - eb.cz) - (a.az + eb.hz);
             if (mp_abs(rw[kP0] - eb.cx) <= eb.hx && mp_abs(rw[kP1] - eb.cy) <= eb.hy && gz > T(0)) {
-                MINKEY[lane * KS] = kSepBit | Key<T>::bits(mp_fma(gz, gz, T(0)));   // the slot is still at its initial value
-                if (ARGS) ARG[lane * AS] = bi;
-                U32 = __builtin_fminf(U32, (float)key_to_sep2<T>(MINKEY[lane * KS]) * (1.0f + 4e-6f));
+                MINKEY[own * KS] = kSepBit | Key<T>::bits(mp_fma(gz, gz, T(0)));   // the slot is still at its initial value
+                if (ARGS) ARG[own * AS] = bi;
+                U32 = __builtin_fminf(U32, (float)key_to_sep2<T>(MINKEY[own * KS]) * (1.0f + 4e-6f));
                 need = false;
             }
         }
-        const unsigned long long m = __builtin_amdgcn_ballot_w64(need);
-        if (need) {
-            const int pos = __builtin_amdgcn_mbcnt_hi((unsigned int)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)m, 0u));
-            if (Q16) reinterpret_cast<unsigned short *>(QUEUE)[pos] = (unsigned short)(((unsigned int)lane << 10) | (unsigned int)bi);
-            else QUEUE[pos] = ((unsigned int)lane << 24) | (unsigned int)bi;
+        push(need, bi);
+    }
+
+
+    // Per-sample seed of the bound (mp_api.hip, cem_solve): the box that decides this collision sample on the MEAN trajectory
+    // of the population the candidate was drawn from.  Evaluated exactly, first, for every lane at once (one full exact
+    // pass), it bounds the lane's clearance from above before the sweep starts, so the sweep queues only boxes that can
+    // still beat a near-final value; without it every box the sweep meets before a lane's first exact pass is queued
+    // against an infinite bound (measured with a perfect bound: 249 -> 73 exact pairs per candidate at config 3,
+    // 137 -> 49 per chunk at B=13 S=101, 779 -> 131 at config 4).  The result does not depend on the seed: the sweep still
+    // queues every box whose bound is not above the lane's value.
+    int sb = -1;
+    if (SEEDED && seed_row) {
+        if (valid) sb = seed_row[k0 + lane];
+        push(sb >= 0, sb);
+        if (qcount > 0) {
+            drain(qcount, 0);
+            qcount = 0;
         }
-        qcount = __builtin_popcountll(m);
     }
 
     // Bound pass over the task's boxes in sorted order.  With several groups a whole group
     // is skipped when no lane of the wave can be closer to its AABB than its current minimum.
+    // (two copies of the sweep: only a seeded launch pays for the comparison with the seed box)
+    auto sweep = [&](auto with_seed) {
+    constexpr bool WS = decltype(with_seed)::value;
     for (int g = 0; g < ngroups; ++g) {
         const BoxRec32 grp = load_box32_uniform(groups, 2 * g);
         MP_STAT_ADD(7, 1);
@@ -446,27 +485,12 @@ __device__ __forceinline__ void clearance_chunk(const AT &a, const BoxRec<T> *bo
         MP_STAT_ADD(1, 1); MP_STAT_ADD(2, gcnt);
         // two boxes per trip (packed fp32): group j of 16 records is pairs 8j ... of the task's pair table
         const int pfirst = (gfirst - n_wide) >> 1, npairs = (gcnt + 1) >> 1;
-        auto push = [&](bool need, int idx) {
-            const unsigned long long m = __builtin_amdgcn_ballot_w64(need);
-            if (m) {
-                if (need) {
-                    const int pos = __builtin_amdgcn_mbcnt_hi((unsigned int)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)m, (unsigned int)qcount));
-                    if (Q16) reinterpret_cast<unsigned short *>(QUEUE)[pos] = (unsigned short)(lane10 | (unsigned int)idx);
-                    else QUEUE[pos] = lane24 | (unsigned int)idx;
-                }
-                qcount += __builtin_popcountll(m);
-                if (qcount >= 64) {
-                    drain(64, qcount - 64);
-                    qcount -= 64;
-                }
-            }
-        };
         // two records in flight, used alternately (unrolled by two: the record being tested and the one being fetched swap
         // roles instead of being copied from one set of scalar registers to the other every trip: config-4 shape -3.7 %)
         auto test2 = [&](const BoxPair32 &bp) {
             const v2f lb2 = aabb_lb2_pair(mlox, mloy, mloz, mhix, mhiy, mhiz, bp);
-            push(lb2.x <= U32, bp.idx0);
-            push(bp.idx1 >= 0 && lb2.y <= U32, bp.idx1);   // against the bound as the first push may have refreshed it
+            push(lb2.x <= U32 && (!WS || bp.idx0 != sb), bp.idx0);   // the seed box has been evaluated
+            push(bp.idx1 >= 0 && lb2.y <= U32 && (!WS || bp.idx1 != sb), bp.idx1);   // against the bound as the first push may have refreshed it
         };
         BoxPair32 ra = load_pair_uniform(pairs, pfirst);
         for (int i = 0; i < npairs; i += 2) {
@@ -476,7 +500,17 @@ __device__ __forceinline__ void clearance_chunk(const AT &a, const BoxRec<T> *bo
             if (i + 1 < npairs) test2(rb);
         }
     }
-    if (qcount > 0) drain(qcount, 0);
+    };
+    if (SEEDED && seed_row) sweep(std::true_type{});
+    else sweep(std::false_type{});
+    // What is left goes into an exact pass of its own, unless another chunk of the trajectory follows: then the entries
+    // stay queued and share a pass with that chunk's first entries (S = 101: 64 + 37 samples, four partly filled passes
+    // become three).
+    if (keep_tail) qcarry = qcount;
+    else {
+        if (qcount > 0) drain(qcount, 0);
+        qcarry = 0;
+    }
     wave_lds_sync();
 }
 
@@ -591,9 +625,9 @@ __global__ void __launch_bounds__(256, (eval_min_waves<T, GRAD, ROT, WV, NW>()))
     for (long long cand = WIDE ? (long long)blockIdx.x : (long long)blockIdx.x * wpb + wib; cand < a.n;
          cand += WIDE ? (long long)gridDim.x : (long long)gridDim.x * wpb) {
         MP_ARGS_REFRESH();
-        long long tl;
+        long long tl, grp = 0;
         if (a.group_size > 0) {
-            const long long grp = cand / a.group_size;
+            grp = cand / a.group_size;
             if (a.group_done && a.group_done[grp]) continue;
             tl = a.group_task ? (long long)a.group_task[grp] : 0;
         } else {
@@ -770,9 +804,15 @@ __global__ void __launch_bounds__(256, (eval_min_waves<T, GRAD, ROT, WV, NW>()))
             const BoxRec32 *groups = a.groups + 2 * ldu(&tk.group_begin);
             const int ngroups = ldu(&tk.group_count);
             const int n_wide = ldu(&tk.n_wide);
+            // entries of different chunks may share an exact pass when a queue entry has room for the trajectory's sample index
+            const bool defer_ok = Sp > 64 && (COMPACT ? a.defer == 1 : a.defer != 0);
+            int qcarry = 0;
+            for (int k0 = 0; k0 < Sp; k0 += 64)
+                clearance_chunk<T, ROT, false, false, NREC, KS, AS, COMPACT, GRAD, !GRAD>(a, boxes, boxes32, a.pairs + ldu(&tk.spair_begin), groups,
+                                                                          ngroups, n_wide, lane, k0, Sp, REC, MINKEY, ARG, QUEUE,
+                                                                          (!GRAD && a.seed) ? a.seed + (size_t)grp * Sp : nullptr, qcarry,
+                                                                          defer_ok, defer_ok && k0 + 64 < Sp);
             for (int k0 = 0; k0 < Sp; k0 += 64) {
-                clearance_chunk<T, ROT, false, false, NREC, KS, AS, COMPACT, GRAD>(a, boxes, boxes32, a.pairs + ldu(&tk.spair_begin), groups,
-                                                                          ngroups, n_wide, lane, k0, Sp, REC, MINKEY + k0 * KS, ARG + k0 * AS, QUEUE);
                 const int k = k0 + lane;
                 if (k < Sp) {
                     const T d = key_to_distance<T>(MINKEY[k * KS]);
@@ -1197,9 +1237,9 @@ __global__ void __launch_bounds__(256, (ROT == 2 ? 2 : MP_CLR_WAVES)) clearance_
     for (long long u = (long long)blockIdx.x * wpb + wib; u < units; u += (long long)gridDim.x * wpb) {
         const long long cand = u / chunks;
         const int k0 = (int)(u - cand * chunks) << 6;
-        long long tl;
+        long long tl, grp = 0;
         if (a.group_size > 0) {
-            const long long grp = cand / a.group_size;
+            grp = cand / a.group_size;
             if (a.group_done && a.group_done[grp]) continue;
             tl = a.group_task ? (long long)a.group_task[grp] : 0;
         } else {
@@ -1251,8 +1291,10 @@ __global__ void __launch_bounds__(256, (ROT == 2 ? 2 : MP_CLR_WAVES)) clearance_
             }
         }
         wave_lds_sync();
-        clearance_chunk<T, ROT, true, true, kChunkRec, 1, 1, false, ARGS>(a, boxes, boxes32, a.pairs + ldu(&tk.spair_begin), groups, ngroups,
-                                                       n_wide, lane, k0, a.Sp, REC, MINKEY, ARG, QUEUE);
+        int qcarry = 0;
+        clearance_chunk<T, ROT, true, true, kChunkRec, 1, 1, false, ARGS, !ARGS>(a, boxes, boxes32, a.pairs + ldu(&tk.spair_begin), groups, ngroups,
+                                                       n_wide, lane, k0, a.Sp, REC, MINKEY, ARG, QUEUE,
+                                                       (!ARGS && a.seed) ? a.seed + (size_t)grp * a.Sp : nullptr, qcarry, false, false);
         if (k < a.Sp) {
             a.pre_d[cand * a.Sp + k] = key_to_distance<T>(MINKEY[lane]);
             if (ARGS) a.pre_arg[cand * a.Sp + k] = ARG[lane];

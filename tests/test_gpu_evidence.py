@@ -307,3 +307,56 @@ def test_plain_bench_command_starts_its_own_ranks():
     r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "64", "--steps", "1", "--warmup", "0"],
                        capture_output=True, text=True, timeout=120, env=env, cwd=str(ROOT))
     assert r.returncode == 2 and "--gpus 64" in r.stderr and not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_bound_seeds_and_shared_exact_passes_change_no_result(native, oracle_lib, dtype, monkeypatch):
+    """Two work-saving devices of the clearance phase decide only WHICH pairs are evaluated exactly and in which pass, never a
+    value: the seeds of a CEM population (deciding boxes of the mean trajectory, MP_SEEDS) and exact passes shared between
+    the 64-sample chunks of a trajectory (MP_DEFER).  Every combination gives bit-identical CEM results and evaluations, and
+    the evaluations match the oracle's clearances exactly, on shapes with two and with four chunks, few and many boxes."""
+    from motion_planning_amd.configs import BASE_CONFIG
+    from motion_planning_amd.problem import build_path_problem
+    from motion_planning_amd.synthetic import random_scene, synthetic_candidates
+
+    def problem(B, S, sub):
+        start, goal = (-1.5, -1.5, 1.5), (1.5, 1.5, 0.4)
+        cfg = dict(BASE_CONFIG)
+        cfg.update(n_samples_curve=S, collision_check_subsample=sub)
+        return build_path_problem(random_scene(B, 3, (0.1, 0.6), start, goal), start, goal, native.build_basis,
+                                  moving_block_size=(0.9, 0.6, 0.6), start_yaw_deg=0.0, goal_yaw_deg=90.0,
+                                  goal_approach_normals=np.array([[0.0, 0.0, 1.0]]), **cfg)
+
+    cases = [(13, 101, 1), (50, 128, 1), (7, 400, 2), (40, 65, 1), (20, 300, 1)]   # (boxes, samples, subsample)
+    results = {}
+    for seeds in ("1", "0"):
+        for defer in ("1", "0"):
+            monkeypatch.setenv("MP_SEEDS", seeds)
+            monkeypatch.setenv("MP_DEFER", defer)
+            monkeypatch.setenv("MP_SPLIT_CLEARANCE", "0")      # the fused kernels: that is where chunks share a queue
+            outs = []
+            for (B, S, sub) in cases:
+                prob = problem(B, S, sub)
+                ctx = native.Context(0, dtype)
+                ctx.set_problem(prob)
+                X = synthetic_candidates(prob, 96, seed=11, dtype=dtype)
+                for kw in (dict(want_grad=True, want_dist=True), dict(want_grad=False, want_terms=False, want_dist=True)):
+                    o = ctx.eval(X, **kw)
+                    outs.append({k: np.array(v) for k, v in o.items() if v is not None})
+                x0 = np.tile(prob.x0, (6, 1)) + 0.05 * np.arange(6)[:, None]
+                r = ctx.cem_solve(x0.astype(dtype), prob.sigma0.astype(dtype), population_size=32, max_iter=12, seed=5)
+                outs.append({k: np.array(v) for k, v in r.items() if isinstance(v, np.ndarray)})
+                if seeds == "1" and defer == "1":
+                    ref = oracle_lib.evaluate(prob, X, dtype=dtype)
+                    np.testing.assert_array_equal(outs[-3]["dist"], ref["dist"])
+                    np.testing.assert_array_equal(outs[-3]["flags"], ref["flags"])
+                    np.testing.assert_array_equal(outs[-2]["dist"], ref["dist"])
+                ctx.close()
+            results[(seeds, defer)] = outs
+    base = results[("0", "0")]
+    for key, outs in results.items():
+        assert len(outs) == len(base)
+        for a, b in zip(outs, base):
+            assert a.keys() == b.keys()
+            for k in a:
+                np.testing.assert_array_equal(a[k], b[k], err_msg=f"seeds/defer {key}: {k}")
