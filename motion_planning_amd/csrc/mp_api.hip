@@ -65,6 +65,9 @@ struct mp_ctx {
 
     // scene
     DevBuf boxes, boxes32, pairs32, groups;
+    DevBuf grid;                  // seed grids of the box ranges (problem data, built by upload_problem)
+    int grid_mode = 1;            // 0: no seed grids (MP_GRID=0, tuning aid / A-B)
+    int grid_cells_per_box = 4;   // resolution of a seed grid: about this many cells per box of the range (MP_GRID_CELLS)
     std::vector<double> h_boxes;  // host copy of the scene (n x 6) for the per-task bound tables
     float scene_radius = 0.f;
     int has_rot = 0;              // 0 axis-aligned scene, 1 some boxes have a yaw of their own, 2 some are tilted
@@ -337,13 +340,16 @@ template <typename T> int upload_problem(mp_ctx *ctx, const mp_task *tasks)
         constexpr int kGroup = MP_GROUP, kGroupMin = 128;
         std::vector<mp::BoxRec32> sb, gr;
         std::vector<mp::BoxPair32> sp;   // the sorted boxes two per record, group by group
-        std::vector<std::array<int, 7>> done;  // begin, count, sbox_begin, group_begin, group_count, n_wide, spair_begin
+        std::vector<std::array<int, 8>> done;  // begin, count, sbox_begin, group_begin, group_count, n_wide, spair_begin, grid
+        struct GridInfo { int begin, nx, ny, nz; float ox, oy, oz, ix, iy, iz; };
+        std::vector<GridInfo> grids;     // one per box range that has a seed grid
+        std::vector<int> cells;          // their cell tables, back to back
         std::unordered_map<long long, size_t> done_at;   // (begin, count) -> index in done (10,000-task batches)
         auto as_float = [](int v) { float f; std::memcpy(&f, &v, 4); return f; };
         for (int i = 0; i < ctx->n_tasks; ++i) {
             const int b0 = tasks[i].box_begin;
             int cnt = tasks[i].box_count;
-            const std::array<int, 7> *hit = nullptr;
+            const std::array<int, 8> *hit = nullptr;
             {
                 const auto it = done_at.find(((long long)b0 << 32) | (unsigned int)cnt);
                 if (it != done_at.end()) hit = &done[it->second];
@@ -476,7 +482,50 @@ template <typename T> int upload_problem(mp_ctx *ctx, const mp_task *tasks)
                     if (m > 0) { rep.lox = centre[(size_t)k + best][0]; rep.loy = centre[(size_t)k + best][1]; rep.loz = centre[(size_t)k + best][2]; }
                     gr.push_back(rep);
                 }
-                done.push_back({b0, cnt_all, sb0, g0 / 2, ((int)gr.size() - g0) / 2, n_wide, sp0});
+                // Seed grid of the range (clearance_chunk): a uniform grid over the AABB of the swept boxes (the wide box is
+                // settled before the seeds), about grid_cells_per_box cells per box, each cell holding the box whose world
+                // AABB is nearest to the cell's centre.  A sample looks up the cell it lies in and evaluates that box first:
+                // its exact value bounds the sample's clearance before the sweep starts.  Only a heuristic: results do not
+                // depend on what a cell holds.
+                int grid_id = -1;
+                if (ctx->grid_mode && c.model == MP_MODEL_BOX && cnt >= 4) {
+                    double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
+                    for (int k : order) {
+                        const double *r = &ctx->h_boxes[(size_t)(b0 + k) * 6];
+                        for (int a = 0; a < 3; ++a) { lo[a] = std::min(lo[a], r[a] - r[3 + a]); hi[a] = std::max(hi[a], r[a] + r[3 + a]); }
+                    }
+                    const double ext[3] = {std::max(hi[0] - lo[0], 1e-6), std::max(hi[1] - lo[1], 1e-6), std::max(hi[2] - lo[2], 1e-6)};
+                    const double target = std::min(8192.0, std::max(64.0, (double)ctx->grid_cells_per_box * cnt));
+                    const double h = std::cbrt(ext[0] * ext[1] * ext[2] / target);   // edge of a cubic cell
+                    int nd[3];
+                    for (int a = 0; a < 3; ++a) nd[a] = (int)std::min(64.0, std::max(1.0, std::ceil(ext[a] / h)));
+                    GridInfo gi{(int)cells.size(), nd[0], nd[1], nd[2], (float)lo[0], (float)lo[1], (float)lo[2],
+                                (float)(nd[0] / ext[0]), (float)(nd[1] / ext[1]), (float)(nd[2] / ext[2])};
+                    std::vector<float> blo((size_t)cnt * 3), bhi((size_t)cnt * 3);
+                    for (int k = 0; k < cnt; ++k) {
+                        const double *r = &ctx->h_boxes[(size_t)(b0 + order[(size_t)k]) * 6];
+                        for (int a = 0; a < 3; ++a) { blo[(size_t)a * cnt + k] = (float)(r[a] - r[3 + a]); bhi[(size_t)a * cnt + k] = (float)(r[a] + r[3 + a]); }
+                    }
+                    const float *lx = blo.data(), *ly = lx + cnt, *lz = ly + cnt, *ux = bhi.data(), *uy = ux + cnt, *uz = uy + cnt;
+                    for (int iz = 0; iz < nd[2]; ++iz)
+                        for (int iy = 0; iy < nd[1]; ++iy)
+                            for (int ix = 0; ix < nd[0]; ++ix) {
+                                const float px = (float)(lo[0] + (ix + 0.5) * ext[0] / nd[0]), py = (float)(lo[1] + (iy + 0.5) * ext[1] / nd[1]),
+                                            pz = (float)(lo[2] + (iz + 0.5) * ext[2] / nd[2]);
+                                int best = 0;
+                                float bd = INFINITY;
+                                for (int k = 0; k < cnt; ++k) {
+                                    const float dx = std::max(std::max(lx[k] - px, px - ux[k]), 0.f), dy = std::max(std::max(ly[k] - py, py - uy[k]), 0.f),
+                                                dz = std::max(std::max(lz[k] - pz, pz - uz[k]), 0.f);
+                                    const float d2 = dx * dx + dy * dy + dz * dz;
+                                    if (d2 < bd) { bd = d2; best = k; }
+                                }
+                                cells.push_back(order[(size_t)best]);
+                            }
+                    grid_id = (int)grids.size();
+                    grids.push_back(gi);
+                }
+                done.push_back({b0, cnt_all, sb0, g0 / 2, ((int)gr.size() - g0) / 2, n_wide, sp0, grid_id});
                 done_at[((long long)b0 << 32) | (unsigned int)cnt_all] = done.size() - 1;
                 hit = &done.back();
             }
@@ -485,7 +534,18 @@ template <typename T> int upload_problem(mp_ctx *ctx, const mp_task *tasks)
             dt[i].group_count = (*hit)[4];
             dt[i].n_wide = (*hit)[5];
             dt[i].spair_begin = (*hit)[6];
+            dt[i].grid_begin = -1;
+            dt[i].gnx = dt[i].gny = dt[i].gnz = 1;
+            dt[i].gox = dt[i].goy = dt[i].goz = 0.f;
+            dt[i].gix = dt[i].giy = dt[i].giz = 0.f;
+            if ((*hit)[7] >= 0) {
+                const GridInfo &gi = grids[(size_t)(*hit)[7]];
+                dt[i].grid_begin = gi.begin; dt[i].gnx = gi.nx; dt[i].gny = gi.ny; dt[i].gnz = gi.nz;
+                dt[i].gox = gi.ox; dt[i].goy = gi.oy; dt[i].goz = gi.oz; dt[i].gix = gi.ix; dt[i].giy = gi.iy; dt[i].giz = gi.iz;
+            }
         }
+        if (cells.empty()) cells.push_back(-1);
+        if ((rc = upload(ctx, ctx->grid, cells.data(), cells.size() * sizeof(int)))) return rc;
         if ((rc = upload(ctx, ctx->boxes32, sb.data(), sb.size() * sizeof(mp::BoxRec32)))) return rc;
         if ((rc = upload(ctx, ctx->groups, gr.data(), gr.size() * sizeof(mp::BoxRec32)))) return rc;
         if ((rc = upload(ctx, ctx->pairs32, sp.data(), sp.size() * sizeof(mp::BoxPair32)))) return rc;
@@ -575,6 +635,7 @@ int launch_eval(mp_ctx *ctx, long long n, const void *X, const int32_t *task_of,
     a.tasks = (const mp::DevTask<T> *)ctx->d_tasks.p; a.boxes = (const mp::BoxRec<T> *)ctx->boxes.p;
     a.boxes32 = (const mp::BoxRec32 *)ctx->boxes32.p; a.pairs = (const mp::BoxPair32 *)ctx->pairs32.p; a.groups = (const mp::BoxRec32 *)ctx->groups.p;
     a.scene_radius = ctx->scene_radius;
+    a.grid = ctx->grid_mode ? (const int *)ctx->grid.p : nullptr;
     a.tilt = (const T *)ctx->tilt.p;
     a.X = (const T *)X; a.task_of = task_of; a.cpt = ctx->cands_per_task; a.n = n;
     a.group_size = group_size; a.group_task = group_task; a.group_done = group_done;
@@ -911,6 +972,8 @@ int mp_create(int device_id, int dtype, mp_ctx **out)
     ctx->device = device_id;
     if (const char *sm = std::getenv("MP_SPLIT_CLEARANCE")) ctx->split_mode = std::atoi(sm) != 0 ? 1 : 0;
     if (const char *sm = std::getenv("MP_SEEDS")) ctx->seed_mode = std::atoi(sm) != 0 ? 1 : 0;
+    if (const char *gm = std::getenv("MP_GRID")) ctx->grid_mode = std::atoi(gm) != 0 ? 1 : 0;
+    if (const char *gc = std::getenv("MP_GRID_CELLS")) ctx->grid_cells_per_box = std::max(1, std::atoi(gc));
     if (const char *sm = std::getenv("MP_DEFER")) ctx->defer_mode = std::atoi(sm) != 0 ? 1 : 0;
     if (const char *wm = std::getenv("MP_WIDE")) ctx->wide_mode = std::atoi(wm) != 0 ? -1 : 0;
     if (const char *ws = std::getenv("MP_WIDE_MIN_S")) ctx->wide_min_s = std::atoi(ws);
@@ -953,7 +1016,7 @@ int mp_destroy(mp_ctx *ctx)
     DeviceGuard guard_;
     (void)guard_.enter(ctx);
     hipStreamSynchronize(ctx->stream);
-    DevBuf *bufs[] = {&ctx->boxes, &ctx->boxes32, &ctx->pairs32, &ctx->groups, &ctx->d_idx, &ctx->d_inv, &ctx->d_mask, &ctx->d_M, &ctx->d_My, &ctx->d_tsched, &ctx->d_tasks,
+    DevBuf *bufs[] = {&ctx->boxes, &ctx->boxes32, &ctx->pairs32, &ctx->groups, &ctx->grid, &ctx->d_idx, &ctx->d_inv, &ctx->d_mask, &ctx->d_M, &ctx->d_My, &ctx->d_tsched, &ctx->d_tasks,
                       &ctx->s_X, &ctx->s_taskof, &ctx->s_cost, &ctx->s_terms, &ctx->s_grad, &ctx->s_minc,
                       &ctx->s_flags, &ctx->s_dist, &ctx->s_aux0, &ctx->s_aux1, &ctx->s_pre_d, &ctx->s_pre_arg, &ctx->d_seed, &ctx->d_seed_d, &ctx->tilt, &ctx->c_X, &ctx->c_vals, &ctx->c_minc,
                       &ctx->c_flags, &ctx->c_mu, &ctx->c_sigma, &ctx->c_bestx, &ctx->c_bestval, &ctx->c_prev, &ctx->c_bminc,

@@ -62,6 +62,10 @@ template <typename T> struct DevTask {
     int group_begin;   // first group of this task in the group table (records 2*group_begin ...)
     int group_count;   // groups of kGroupSize consecutive sorted boxes (1 group: no group test)
     int n_wide;        // 1: record 0 of the sorted table is a wide box handled before the sweep (clearance_chunk)
+    // seed grid of the task's box range (clearance_chunk): cell (ix, iy, iz) of a uniform grid over the boxes' AABB holds the box
+    // (index relative to the range) nearest to the cell's centre; grid_begin < 0: the range has none
+    int grid_begin, gnx, gny, gnz;
+    float gox, goy, goz, gix, giy, giz;   // origin and 1 / cell size per axis
     T xref[64];        // initial value of optimisation variable o (the via / yaw control it deviates from), o < D <= 56
 };
 
@@ -113,6 +117,7 @@ template <typename T> struct EvalArgs {
     int *pre_arg;  // its deciding box, relative to the task's range (-1: none)
     int defer;         // fused box-model launches with several 64-sample chunks: queue entries carry the trajectory's sample index
                        // (host: n_safe and the tasks' box counts fit the entry; clearance_chunk)
+    const int *grid;   // seed grids of the tasks' box ranges, one int per cell (DevTask::grid_begin)
     const int *seed;   // cost-only launches of candidate groups (CEM populations): [n_groups x Sp] deciding box of every collision
                        // sample on the group's mean trajectory (nullptr: no seeds; set only together with group_size > 0)
 };
@@ -262,8 +267,8 @@ constexpr int kChunkRec = 7;   // record of clearance_kernel: P0 P1 P2 YW CC SS 
 // consecutive slots (1: an array; NREC: the keys are a field of the fp64 records).
 // AS: the same for the deciding-box words (in ints).  Q16: work-queue entries are 16 bits (lane << 10 | box; every task < 1024 boxes).
 // ARGS: keep the deciding box of every sample (the gradient needs it; cost-only launches skip the second atomic and its barriers).
-template <typename T, int ROT, bool LOCAL, bool SEED, int NREC, int KS = 1, int AS = 1, bool Q16 = false, bool ARGS = true, bool SEEDED = false, typename AT>
-__device__ __forceinline__ void clearance_chunk(const AT &a, const BoxRec<T> *boxes, const BoxRec32 *boxes32, const BoxPair32 *pairs,
+template <typename T, int ROT, bool LOCAL, bool SEED, int NREC, int KS = 1, int AS = 1, bool Q16 = false, bool ARGS = true, bool SEEDED = false, typename AT, typename TK>
+__device__ __forceinline__ void clearance_chunk(const AT &a, const TK &tk, const BoxRec<T> *boxes, const BoxRec32 *boxes32, const BoxPair32 *pairs,
                                                 const BoxRec32 *groups, int ngroups, int n_wide, int lane, int k0, int Sp, T *REC,
                                                 unsigned long long *MINKEY, int *ARG, unsigned int *QUEUE, const int *seed_row,
                                                 int &qcarry, bool defer, bool keep_tail)
@@ -316,7 +321,10 @@ __device__ __forceinline__ void clearance_chunk(const AT &a, const BoxRec<T> *bo
     // qcount + (needing lanes below this one), which v_mbcnt delivers with qcount as its start value.
     int qcount = qcarry;  // wave-uniform; entries a previous chunk of the trajectory left behind (defer)
     MP_STAT_ADD(0, 1);
-    if (SEED && ngroups > 1 && !(SEEDED && seed_row)) {
+    // a seed box per sample (below): from the caller's row, else from the task's seed grid
+    const int grid_begin = SEEDED ? ldu(&tk.grid_begin) : -1;
+    const bool seeded = SEEDED && (seed_row || (grid_begin >= 0 && a.grid));
+    if (SEED && ngroups > 1 && !seeded) {
         // Seed of the upper bound: the mover's centre lies in the mover and a box's centre in the box, so the scene
         // value is at most the distance from this sample to the centre of any box.  One representative box per
         // group (record 2g+1), coordinates inflated by the slack, keeps the first groups of the sweep from
@@ -432,9 +440,11 @@ __device__ __forceinline__ void clearance_chunk(const AT &a, const BoxRec<T> *bo
     // minus the mover's smaller half extent), so with a positive z gap the pair value is gz^2, computed exactly as
     // pair_key would, and the lane settles the pair on its own sample slot; the other lanes queue it as usual
     // through the queue.
+    int wide_bi = -1;
     if (!ROT && n_wide > 0) {
         const BoxRec32 bx = load_box32_uniform(boxes32, 0);
         const int bi = __float_as_int(bx.pad0);
+        wide_bi = bi;
         const BoxRec<T> eb = load_box_uniform(boxes, bi);
         bool need = aabb_lb2(mlox, mloy, mloz, mhix, mhiy, mhiz, bx) <= U32;
         if (need && a.ax > T(1e-3) && a.ay > T(1e-3)) {
@@ -452,17 +462,30 @@ __device__ __forceinline__ void clearance_chunk(const AT &a, const BoxRec<T> *bo
     }
 
 
-    // Per-sample seed of the bound (mp_api.hip, cem_solve): the box that decides this collision sample on the MEAN trajectory
-    // of the population the candidate was drawn from.  Evaluated exactly, first, for every lane at once (one full exact
-    // pass), it bounds the lane's clearance from above before the sweep starts, so the sweep queues only boxes that can
-    // still beat a near-final value; without it every box the sweep meets before a lane's first exact pass is queued
-    // against an infinite bound (measured with a perfect bound: 249 -> 73 exact pairs per candidate at config 3,
-    // 137 -> 49 per chunk at B=13 S=101, 779 -> 131 at config 4).  The result does not depend on the seed: the sweep still
-    // queues every box whose bound is not above the lane's value.
+    // Per-sample seed of the bound: a box that is likely to be the sample's nearest, evaluated exactly, first, for every lane at
+    // once (one full exact pass).  It bounds the lane's clearance from above before the sweep starts, so the sweep queues only
+    // boxes that can still beat a near-final value; without it every box the sweep meets before a lane's first exact pass is
+    // queued against an infinite bound (measured with a perfect seed: 249 -> 73 exact pairs per candidate at config 3,
+    // 137 -> 49 per chunk at B=13 S=101, 779 -> 131 at config 4).  Sources: the box that decides this collision sample on the
+    // MEAN trajectory of the population the candidate was drawn from (mp_api.hip, cem_solve), else the box nearest to the
+    // centre of the cell the sample lies in, looked up in the uniform grid the host builds per box range (mp_api.hip,
+    // upload_problem).  The result does not depend on the seed: the sweep still queues every box whose bound is not above
+    // the lane's value.
     int sb = -1;
-    if (SEEDED && seed_row) {
-        if (valid) sb = seed_row[k0 + lane];
-        push(sb >= 0, sb);
+    if (seeded) {
+        if (seed_row) {
+            if (valid) sb = seed_row[k0 + lane];
+        } else {
+            const int gnx = ldu(&tk.gnx), gny = ldu(&tk.gny), gnz = ldu(&tk.gnz);
+            const float fx = (px32 - ldu(&tk.gox)) * ldu(&tk.gix), fy = (py32 - ldu(&tk.goy)) * ldu(&tk.giy),
+                        fz = (pz32 - ldu(&tk.goz)) * ldu(&tk.giz);
+            // clamped in floating point first (a far-away or NaN sample must not overflow the conversion)
+            const int ix = (int)__builtin_fminf(__builtin_fmaxf(fx, 0.f), (float)(gnx - 1));
+            const int iy = (int)__builtin_fminf(__builtin_fmaxf(fy, 0.f), (float)(gny - 1));
+            const int iz = (int)__builtin_fminf(__builtin_fmaxf(fz, 0.f), (float)(gnz - 1));
+            if (valid) sb = a.grid[grid_begin + (iz * gny + iy) * gnx + ix];
+        }
+        push(sb >= 0 && sb != wide_bi, sb);   // (the wide box has been settled or queued above for every lane)
         if (qcount > 0) {
             drain(qcount, 0);
             qcount = 0;
@@ -474,13 +497,13 @@ __device__ __forceinline__ void clearance_chunk(const AT &a, const BoxRec<T> *bo
     // (two copies of the sweep: only a seeded launch pays for the comparison with the seed box)
     auto sweep = [&](auto with_seed) {
     constexpr bool WS = decltype(with_seed)::value;
-    for (int g = 0; g < ngroups; ++g) {
+    auto visit = [&](int g) {
         const BoxRec32 grp = load_box32_uniform(groups, 2 * g);
         MP_STAT_ADD(7, 1);
         const int gfirst = __float_as_int(grp.pad0), gcnt = __float_as_int(grp.pad1);
         if (ngroups > 1) {
             const float lbg = aabb_lb2(mlox, mloy, mloz, mhix, mhiy, mhiz, grp);
-            if (!__builtin_amdgcn_ballot_w64(lbg <= U32)) continue;
+            if (!__builtin_amdgcn_ballot_w64(lbg <= U32)) return;
         }
         MP_STAT_ADD(1, 1); MP_STAT_ADD(2, gcnt);
         // two boxes per trip (packed fp32): group j of 16 records is pairs 8j ... of the task's pair table
@@ -499,9 +522,41 @@ __device__ __forceinline__ void clearance_chunk(const AT &a, const BoxRec<T> *bo
             ra = load_pair_uniform(pairs, pfirst + (i + 2 < npairs ? i + 2 : i));
             if (i + 1 < npairs) test2(rb);
         }
+    };
+    if (SEED && ngroups > 1) {
+        // Group prefilter (the split kernel; scenes large enough to have groups): 64 groups per trip, one per LANE, against
+        // the one region every lane's search is confined to - the union over the wave's samples of the mover's AABB
+        // inflated by r = sqrt(U32) - and only the groups that touch it get the per-sample test above.  Conservative: a
+        // group some lane needs has lb2 <= U32 there, so along every axis its gap to that lane's AABB is at most
+        // sqrt(U32) (each squared gap is one of the non-negative terms of lb2, and fp32 addition of a non-negative term
+        // never lowers a sum), i.e. the group's AABB touches [mlo - r, mhi + r]; r carries 1e-5 relative and the
+        // slack on top, far more than the roundings of the additions below (2.4e-7 of the coordinates).  The bounds
+        // only tighten while the sweep runs, so a region taken here stays valid (if no longer minimal) to its end.
+        const float rr = valid ? __builtin_fmaf(__builtin_sqrtf(__builtin_fmaxf(U32, 0.f)), 1.0f + 1e-5f, slack) : 0.f;
+        const float inf = __builtin_huge_valf();
+        const float ulox = wave_min(valid ? mlox - rr : inf), uloy = wave_min(valid ? mloy - rr : inf),
+                    uloz = wave_min(valid ? mloz - rr : inf);
+        const float uhix = -wave_min(valid ? -(mhix + rr) : inf), uhiy = -wave_min(valid ? -(mhiy + rr) : inf),
+                    uhiz = -wave_min(valid ? -(mhiz + rr) : inf);
+        for (int g0 = 0; g0 < ngroups; g0 += 64) {
+            const int gi = g0 + lane;
+            bool hit = false;
+            if (gi < ngroups) {
+                const BoxRec32 &gr = groups[2 * gi];
+                hit = gr.lox <= uhix && gr.hix >= ulox && gr.loy <= uhiy && gr.hiy >= uloy && gr.loz <= uhiz && gr.hiz >= uloz;
+            }
+            unsigned long long m = __builtin_amdgcn_ballot_w64(hit);
+            while (m) {
+                const int g = g0 + __builtin_ctzll(m);
+                m &= m - 1;
+                visit(g);
+            }
+        }
+    } else {
+        for (int g = 0; g < ngroups; ++g) visit(g);
     }
     };
-    if (SEEDED && seed_row) sweep(std::true_type{});
+    if (seeded) sweep(std::true_type{});
     else sweep(std::false_type{});
     // What is left goes into an exact pass of its own, unless another chunk of the trajectory follows: then the entries
     // stay queued and share a pass with that chunk's first entries (S = 101: 64 + 37 samples, four partly filled passes
@@ -808,9 +863,9 @@ __global__ void __launch_bounds__(256, (eval_min_waves<T, GRAD, ROT, WV, NW>()))
             const bool defer_ok = Sp > 64 && (COMPACT ? a.defer == 1 : a.defer != 0);
             int qcarry = 0;
             for (int k0 = 0; k0 < Sp; k0 += 64)
-                clearance_chunk<T, ROT, false, false, NREC, KS, AS, COMPACT, GRAD, !GRAD>(a, boxes, boxes32, a.pairs + ldu(&tk.spair_begin), groups,
+                clearance_chunk<T, ROT, false, false, NREC, KS, AS, COMPACT, GRAD, (ROT < 2)>(a, tk, boxes, boxes32, a.pairs + ldu(&tk.spair_begin), groups,
                                                                           ngroups, n_wide, lane, k0, Sp, REC, MINKEY, ARG, QUEUE,
-                                                                          (!GRAD && a.seed) ? a.seed + (size_t)grp * Sp : nullptr, qcarry,
+                                                                          a.seed ? a.seed + (size_t)grp * Sp : nullptr, qcarry,
                                                                           defer_ok, defer_ok && k0 + 64 < Sp);
             for (int k0 = 0; k0 < Sp; k0 += 64) {
                 const int k = k0 + lane;
@@ -1292,9 +1347,9 @@ __global__ void __launch_bounds__(256, (ROT == 2 ? 2 : MP_CLR_WAVES)) clearance_
         }
         wave_lds_sync();
         int qcarry = 0;
-        clearance_chunk<T, ROT, true, true, kChunkRec, 1, 1, false, ARGS, !ARGS>(a, boxes, boxes32, a.pairs + ldu(&tk.spair_begin), groups, ngroups,
+        clearance_chunk<T, ROT, true, true, kChunkRec, 1, 1, false, ARGS, (ROT < 2)>(a, tk, boxes, boxes32, a.pairs + ldu(&tk.spair_begin), groups, ngroups,
                                                        n_wide, lane, k0, a.Sp, REC, MINKEY, ARG, QUEUE,
-                                                       (!ARGS && a.seed) ? a.seed + (size_t)grp * a.Sp : nullptr, qcarry, false, false);
+                                                       a.seed ? a.seed + (size_t)grp * a.Sp : nullptr, qcarry, false, false);
         if (k < a.Sp) {
             a.pre_d[cand * a.Sp + k] = key_to_distance<T>(MINKEY[lane]);
             if (ARGS) a.pre_arg[cand * a.Sp + k] = ARG[lane];
