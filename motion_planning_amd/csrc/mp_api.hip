@@ -67,6 +67,7 @@ struct mp_ctx {
     DevBuf boxes, boxes32, pairs32, groups;
     DevBuf grid;                  // seed grids of the box ranges (problem data, built by upload_problem)
     int grid_mode = 1;            // 0: no seed grids (MP_GRID=0, tuning aid / A-B)
+    int group_small = 4, group_large = 8;   // boxes per group of the bound tables below / from 1,000 boxes per range (MP_GROUP_SMALL / MP_GROUP_LARGE, even)
     int grid_cells_per_box = 4;   // resolution of a seed grid: about this many cells per box of the range (MP_GRID_CELLS)
     std::vector<double> h_boxes;  // host copy of the scene (n x 6) for the per-task bound tables
     float scene_radius = 0.f;
@@ -334,10 +335,12 @@ template <typename T> int upload_problem(mp_ctx *ctx, const mp_task *tasks)
     // Bound-pass tables: per distinct box range, the boxes sorted along a Morton curve (fp32 records,
     // pad0 = index relative to the range) and the AABBs of groups of kGroup consecutive boxes.
     {
-#ifndef MP_GROUP
-#define MP_GROUP 16
-#endif
-        constexpr int kGroup = MP_GROUP, kGroupMin = 128;
+        // Group size (even: the pair table is read group by group).  With the seed grid and the group prefilter of the split
+        // kernel small groups win (round 2, neither: 16).  Measured on MI355X, clearance_kernel, groups of 4 / 6 / 8 / 16:
+        // config-4 shard (2,000 boxes, S=256) 4.72 / 4.83 / 4.65 / 5.57 ms; B=2,000 S=64 cost+grad 0.487 / 0.481 / 0.453 / 0.499 ms;
+        // B=300 S=101 0.263 / 0.275 / 0.269 / 0.291 ms; B=200 S=64 0.279 / 0.291 / 0.293 / 0.300 ms.
+        constexpr int kGroupMin = 128;
+        const int group_small = ctx->group_small, group_large = ctx->group_large;
         std::vector<mp::BoxRec32> sb, gr;
         std::vector<mp::BoxPair32> sp;   // the sorted boxes two per record, group by group
         std::vector<std::array<int, 8>> done;  // begin, count, sbox_begin, group_begin, group_count, n_wide, spair_begin, grid
@@ -374,6 +377,7 @@ template <typename T> int upload_problem(mp_ctx *ctx, const mp_task *tasks)
                     if (k != wide) order.push_back(k);
                 const int cnt_all = cnt;
                 cnt -= n_wide;   // from here on: the boxes that go through the sorted / grouped sweep
+                const int kGroup = cnt >= 1000 ? group_large : group_small;
                 if (cnt >= kGroupMin) {
                     double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
                     for (int k : order)
@@ -973,6 +977,8 @@ int mp_create(int device_id, int dtype, mp_ctx **out)
     if (const char *sm = std::getenv("MP_SPLIT_CLEARANCE")) ctx->split_mode = std::atoi(sm) != 0 ? 1 : 0;
     if (const char *sm = std::getenv("MP_SEEDS")) ctx->seed_mode = std::atoi(sm) != 0 ? 1 : 0;
     if (const char *gm = std::getenv("MP_GRID")) ctx->grid_mode = std::atoi(gm) != 0 ? 1 : 0;
+    if (const char *gs = std::getenv("MP_GROUP_SMALL")) ctx->group_small = std::max(2, std::atoi(gs) & ~1);
+    if (const char *gl = std::getenv("MP_GROUP_LARGE")) ctx->group_large = std::max(2, std::atoi(gl) & ~1);
     if (const char *gc = std::getenv("MP_GRID_CELLS")) ctx->grid_cells_per_box = std::max(1, std::atoi(gc));
     if (const char *sm = std::getenv("MP_DEFER")) ctx->defer_mode = std::atoi(sm) != 0 ? 1 : 0;
     if (const char *wm = std::getenv("MP_WIDE")) ctx->wide_mode = std::atoi(wm) != 0 ? -1 : 0;
