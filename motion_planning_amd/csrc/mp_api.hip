@@ -68,7 +68,7 @@ struct mp_ctx {
     DevBuf grid;                  // seed grids of the box ranges (problem data, built by upload_problem)
     int grid_mode = 1;            // 0: no seed grids (MP_GRID=0, tuning aid / A-B)
     int group_small = 4, group_large = 8;   // boxes per group of the bound tables below / from 1,000 boxes per range (MP_GROUP_SMALL / MP_GROUP_LARGE, even)
-    int grid_cells_per_box = 4;   // resolution of a seed grid: about this many cells per box of the range (MP_GRID_CELLS)
+    int grid_cells_per_box = 16;   // resolution of a seed grid: about this many cells per box of the range (MP_GRID_CELLS)
     std::vector<double> h_boxes;  // host copy of the scene (n x 6) for the per-task bound tables
     float scene_radius = 0.f;
     int has_rot = 0;              // 0 axis-aligned scene, 1 some boxes have a yaw of their own, 2 some are tilted
@@ -505,12 +505,17 @@ template <typename T> int upload_problem(mp_ctx *ctx, const mp_task *tasks)
                     for (int a = 0; a < 3; ++a) nd[a] = (int)std::min(64.0, std::max(1.0, std::ceil(ext[a] / h)));
                     GridInfo gi{(int)cells.size(), nd[0], nd[1], nd[2], (float)lo[0], (float)lo[1], (float)lo[2],
                                 (float)(nd[0] / ext[0]), (float)(nd[1] / ext[1]), (float)(nd[2] / ext[2])};
-                    std::vector<float> blo((size_t)cnt * 3), bhi((size_t)cnt * 3);
+                    // per box the centre and the half extents of (box + mover): a sample's clearance to a box is about the signed
+                    // distance of the mover's centre to the box inflated by the mover (its footprint taken as a square of the mean of
+                    // its two half sides, the yaw being unknown here); negative inside, where the deepest box is the best seed
+                    const float hm[3] = {(float)(0.5 * (c.half_extents[0] + c.half_extents[1])), (float)(0.5 * (c.half_extents[0] + c.half_extents[1])),
+                                         (float)c.half_extents[2]};
+                    std::vector<float> bc((size_t)cnt * 3), bh((size_t)cnt * 3);
                     for (int k = 0; k < cnt; ++k) {
                         const double *r = &ctx->h_boxes[(size_t)(b0 + order[(size_t)k]) * 6];
-                        for (int a = 0; a < 3; ++a) { blo[(size_t)a * cnt + k] = (float)(r[a] - r[3 + a]); bhi[(size_t)a * cnt + k] = (float)(r[a] + r[3 + a]); }
+                        for (int a = 0; a < 3; ++a) { bc[(size_t)a * cnt + k] = (float)r[a]; bh[(size_t)a * cnt + k] = (float)r[3 + a] + hm[a]; }
                     }
-                    const float *lx = blo.data(), *ly = lx + cnt, *lz = ly + cnt, *ux = bhi.data(), *uy = ux + cnt, *uz = uy + cnt;
+                    const float *cx = bc.data(), *cy = cx + cnt, *cz = cy + cnt, *ex = bh.data(), *ey = ex + cnt, *ez = ey + cnt;
                     for (int iz = 0; iz < nd[2]; ++iz)
                         for (int iy = 0; iy < nd[1]; ++iy)
                             for (int ix = 0; ix < nd[0]; ++ix) {
@@ -519,10 +524,11 @@ template <typename T> int upload_problem(mp_ctx *ctx, const mp_task *tasks)
                                 int best = 0;
                                 float bd = INFINITY;
                                 for (int k = 0; k < cnt; ++k) {
-                                    const float dx = std::max(std::max(lx[k] - px, px - ux[k]), 0.f), dy = std::max(std::max(ly[k] - py, py - uy[k]), 0.f),
-                                                dz = std::max(std::max(lz[k] - pz, pz - uz[k]), 0.f);
-                                    const float d2 = dx * dx + dy * dy + dz * dz;
-                                    if (d2 < bd) { bd = d2; best = k; }
+                                    const float qx = std::fabs(px - cx[k]) - ex[k], qy = std::fabs(py - cy[k]) - ey[k], qz = std::fabs(pz - cz[k]) - ez[k];
+                                    const float ox = std::max(qx, 0.f), oy = std::max(qy, 0.f), oz = std::max(qz, 0.f);
+                                    const float out2 = ox * ox + oy * oy + oz * oz;
+                                    const float sd = out2 > 0.f ? std::sqrt(out2) : std::max(qx, std::max(qy, qz));
+                                    if (sd < bd) { bd = sd; best = k; }
                                 }
                                 cells.push_back(order[(size_t)best]);
                             }

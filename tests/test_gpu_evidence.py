@@ -360,3 +360,64 @@ def test_bound_seeds_and_shared_exact_passes_change_no_result(native, oracle_lib
             assert a.keys() == b.keys()
             for k in a:
                 np.testing.assert_array_equal(a[k], b[k], err_msg=f"seeds/defer {key}: {k}")
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_seed_grid_group_size_and_prefilter_change_no_result(native, oracle_lib, dtype, monkeypatch):
+    """The seed grid (MP_GRID: per sample the box nearest to its grid cell is evaluated first), its resolution (MP_GRID_CELLS),
+    the size of the box groups (MP_GROUP_SMALL / MP_GROUP_LARGE) and, with them, the lane-per-group prefilter of the split kernel
+    only decide which pairs are evaluated and when: clearances, deciding-box gradients, costs and flags are the same bits under
+    every setting, fused and split, on axis-aligned and yaw-rotated scenes with and without groups, and the clearances equal
+    the brute-force oracle's."""
+    from motion_planning_amd.configs import BASE_CONFIG
+    from motion_planning_amd.problem import build_path_problem
+    from motion_planning_amd.synthetic import random_scene, synthetic_candidates
+
+    def problem(B, S, sub, size, rotated):
+        start, goal = (-1.5, -1.5, 1.5), (1.5, 1.5, 0.4)
+        cfg = dict(BASE_CONFIG)
+        cfg.update(n_samples_curve=S, collision_check_subsample=sub)
+        scene = random_scene(B, 4, size, start, goal)
+        if rotated:   # every third box gets a yaw of its own
+            for i, blk in enumerate(scene.blocks):
+                if i % 3 == 1:
+                    h = 0.5 * np.deg2rad(17.0 * i)
+                    blk.quat = (0.0, 0.0, float(np.sin(h)), float(np.cos(h)))
+        return build_path_problem(scene, start, goal, native.build_basis, moving_block_size=(0.9, 0.6, 0.6), start_yaw_deg=0.0,
+                                  goal_yaw_deg=90.0, goal_approach_normals=np.array([[0.0, 0.0, 1.0]]), **cfg)
+
+    # (boxes, samples, subsample, box sizes, rotated, split): no grid (< 4 swept boxes), fused, split without / with groups
+    cases = [(3, 64, 1, (0.1, 0.6), False, "0"), (50, 64, 1, (0.1, 0.6), False, "0"), (50, 101, 2, (0.1, 0.6), True, "0"),
+             (90, 130, 1, (0.1, 0.5), False, "1"), (400, 64, 1, (0.05, 0.3), False, "1"), (1300, 96, 1, (0.05, 0.25), True, "1")]
+    settings = [dict(MP_GRID="0"), dict(MP_GRID="1"), dict(MP_GRID="1", MP_GRID_CELLS="1"),
+                dict(MP_GRID="1", MP_GROUP_SMALL="16", MP_GROUP_LARGE="16"), dict(MP_GRID="0", MP_GROUP_SMALL="2", MP_GROUP_LARGE="6")]
+    results = []
+    for si, env in enumerate(settings):
+        for k in ("MP_GRID", "MP_GRID_CELLS", "MP_GROUP_SMALL", "MP_GROUP_LARGE"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        outs = []
+        for (B, S, sub, size, rotated, split) in cases:
+            monkeypatch.setenv("MP_SPLIT_CLEARANCE", split)
+            prob = problem(B, S, sub, size, rotated)
+            ctx = native.Context(0, dtype)
+            ctx.set_problem(prob)
+            X = synthetic_candidates(prob, 80, seed=3, dtype=dtype)
+            for kw in (dict(want_grad=True, want_dist=True), dict(want_grad=False, want_terms=False, want_dist=True)):
+                o = ctx.eval(X, **kw)
+                outs.append({k: np.array(v) for k, v in o.items() if v is not None})
+            if si == 1:
+                ref = oracle_lib.evaluate(prob, X, dtype=dtype)
+                np.testing.assert_array_equal(outs[-2]["dist"], ref["dist"])
+                np.testing.assert_array_equal(outs[-2]["flags"], ref["flags"])
+                np.testing.assert_array_equal(outs[-1]["dist"], ref["dist"])
+                tol = 1e-9 if dtype == np.float64 else 2e-3
+                np.testing.assert_allclose(outs[-2]["grad"], ref["grad"], rtol=tol, atol=tol * max(1.0, float(np.abs(ref["grad"]).max())))
+            ctx.close()
+        results.append(outs)
+    for si, outs in enumerate(results[1:], 1):
+        for a, b in zip(outs, results[0]):
+            assert a.keys() == b.keys()
+            for k in a:
+                np.testing.assert_array_equal(a[k], b[k], err_msg=f"setting {settings[si]}: {k}")
