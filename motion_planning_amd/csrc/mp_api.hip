@@ -67,6 +67,7 @@ struct mp_ctx {
     DevBuf boxes, boxes32, pairs32, groups;
     DevBuf grid;                  // seed grids of the box ranges (problem data, built by upload_problem)
     int grid_mode = 1;            // 0: no seed grids (MP_GRID=0, tuning aid / A-B)
+    int group_min = 0;     // > 0: box ranges from this size on are sorted along a Morton curve and grouped (MP_GROUP_MIN; 0: rule in upload_problem)
     int group_small = 4, group_large = 8;   // boxes per group of the bound tables below / from 1,000 boxes per range (MP_GROUP_SMALL / MP_GROUP_LARGE, even)
     int grid_cells_per_box = 16;   // resolution of a seed grid: about this many cells per box of the range (MP_GRID_CELLS)
     std::vector<double> h_boxes;  // host copy of the scene (n x 6) for the per-task bound tables
@@ -339,7 +340,10 @@ template <typename T> int upload_problem(mp_ctx *ctx, const mp_task *tasks)
         // kernel small groups win (round 2, neither: 16).  Measured on MI355X, clearance_kernel, groups of 4 / 6 / 8 / 16:
         // config-4 shard (2,000 boxes, S=256) 4.72 / 4.83 / 4.65 / 5.57 ms; B=2,000 S=64 cost+grad 0.487 / 0.481 / 0.453 / 0.499 ms;
         // B=300 S=101 0.263 / 0.275 / 0.269 / 0.291 ms; B=200 S=64 0.279 / 0.291 / 0.293 / 0.300 ms.
-        constexpr int kGroupMin = 128;
+        // Ranges from 128 boxes on are grouped; from 32 on when trajectories have more than one 64-sample chunk: those launches
+        // run the split kernel (launch_eval), whose prefilter makes groups pay earlier (B=64 S=256 cost+grad 0.344 -> 0.316 ms,
+        // B=50 S=101 0.336 -> 0.332), while the fused one-chunk kernel loses with them (config 3 0.296 -> 0.303 ms).
+        const int kGroupMin = ctx->group_min > 0 ? ctx->group_min : (c.n_safe > 64 ? 32 : 128);
         const int group_small = ctx->group_small, group_large = ctx->group_large;
         std::vector<mp::BoxRec32> sb, gr;
         std::vector<mp::BoxPair32> sp;   // the sorted boxes two per record, group by group
@@ -983,6 +987,7 @@ int mp_create(int device_id, int dtype, mp_ctx **out)
     if (const char *sm = std::getenv("MP_SPLIT_CLEARANCE")) ctx->split_mode = std::atoi(sm) != 0 ? 1 : 0;
     if (const char *sm = std::getenv("MP_SEEDS")) ctx->seed_mode = std::atoi(sm) != 0 ? 1 : 0;
     if (const char *gm = std::getenv("MP_GRID")) ctx->grid_mode = std::atoi(gm) != 0 ? 1 : 0;
+    if (const char *gm = std::getenv("MP_GROUP_MIN")) ctx->group_min = std::max(4, std::atoi(gm));
     if (const char *gs = std::getenv("MP_GROUP_SMALL")) ctx->group_small = std::max(2, std::atoi(gs) & ~1);
     if (const char *gl = std::getenv("MP_GROUP_LARGE")) ctx->group_large = std::max(2, std::atoi(gl) & ~1);
     if (const char *gc = std::getenv("MP_GRID_CELLS")) ctx->grid_cells_per_box = std::max(1, std::atoi(gc));
