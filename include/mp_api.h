@@ -20,6 +20,7 @@
 #ifndef MP_API_H
 #define MP_API_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -297,6 +298,22 @@ typedef struct mp_cem_options {
 int mp_cem_solve(mp_ctx *ctx, int64_t n_inst, const int32_t *task_of_inst, const void *x0, const void *sigma0,
                  const mp_cem_options *opt, const void *noise, void *best_x, void *best_val, int32_t *nit,
                  void *best_min_clear, uint8_t *best_flags, int mem);
+
+/* ---- the collective of a sharded job (SURVEY.md 8b `mp_allgather_best`, 8e) ---------------------------------
+ * No counterpart in the reference (it is one process).  Candidates / scenarios are sharded over GPUs by
+ * index, one process and one context per GPU; the only exchange of a job is one all-gather of every rank's results.
+ * The Python host does it with torch.distributed (motion_planning_amd/batch.py); this is the same step for callers that
+ * hold an RCCL communicator of their own:
+ *
+ *   nccl_comm       the caller's ncclComm_t (made with ncclCommInitRank on this context's GPU)
+ *   send            DEVICE buffer of bytes_per_rank bytes: this rank's results, any layout (e.g. cost | min_clear | flags
+ *                   of its candidates, written by mp_eval(MP_MEM_DEVICE) on this context)
+ *   recv            DEVICE buffer of n_ranks * bytes_per_rank bytes: rank r's bytes at offset r * bytes_per_rank
+ *
+ * One ncclAllGather of raw bytes on the context's stream, ordered behind the kernels that wrote `send`; asynchronous
+ * (mp_synchronize waits for it).  RCCL is not linked into the library: ncclAllGather is looked up in the calling process
+ * (the caller created the communicator, so its librccl is loaded); MP_E_UNSUPPORTED when there is none. */
+int mp_allgather_results(mp_ctx *ctx, void *nccl_comm, const void *send, void *recv, size_t bytes_per_rank);
 
 #ifdef __cplusplus
 }

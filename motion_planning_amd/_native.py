@@ -66,10 +66,11 @@ def load():
     lib.mp_eval_noalloc.argtypes = [vp, i64, vp, vp, vp, vp, vp, vp]
     lib.mp_point_sdf.argtypes = [vp, i64, vp, C.c_double, i32, i32, vp, C.c_int]
     lib.mp_box_sdf.argtypes = [vp, i64, vp, vp, vp, i32, i32, vp, C.c_int]
+    lib.mp_allgather_results.argtypes = [vp, vp, vp, vp, C.c_size_t]
     lib.mp_cem_solve.argtypes = [vp, i64, vp, vp, vp, C.POINTER(abi.MpCemOptions), vp, vp, vp, vp, vp, vp, C.c_int]
     for name in ("mp_create", "mp_destroy", "mp_set_stream", "mp_use_own_stream", "mp_synchronize", "mp_timer_start", "mp_timer_stop",
                  "mp_set_scene", "mp_set_problem", "mp_build_basis", "mp_get_basis", "mp_set_cands_per_task",
-                 "mp_eval", "mp_eval_noalloc", "mp_point_sdf", "mp_box_sdf", "mp_cem_solve"):
+                 "mp_eval", "mp_eval_noalloc", "mp_point_sdf", "mp_box_sdf", "mp_cem_solve", "mp_allgather_results"):
         getattr(lib, name).restype = C.c_int
     if lib.mp_api_version() != abi.MP_API_VERSION:
         raise ImportError("libmp_hip.so was built from a different mp_api.h version")

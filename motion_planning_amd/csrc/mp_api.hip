@@ -2,6 +2,7 @@
 // buffers, problem upload, kernel launches.  There is no CPU compute path in this file:
 // without a HIP device mp_create fails and nothing else can be called.
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
 
 #include <algorithm>
 #include <array>
@@ -1379,6 +1380,48 @@ int mp_eval_noalloc(mp_ctx *ctx, int64_t n, const void *X, const int32_t *task_o
         ord.last = ctx->stream;
         ord.recorded = true;
     }
+    return MP_OK;
+}
+
+// ---- the one collective of a sharded job, for callers without torch.distributed ------------------------
+// RCCL is not linked: its ncclAllGather is looked up at the first call, in the process first (the caller made the
+// communicator, so its RCCL is loaded), then by name.  ncclDataType_t ncclUint8 = 1, ncclResult_t ncclSuccess = 0.
+namespace {
+typedef int (*nccl_allgather_fn)(const void *, void *, size_t, int, void *, hipStream_t);
+typedef const char *(*nccl_errstr_fn)(int);
+std::mutex g_rccl_mutex;
+nccl_allgather_fn g_nccl_allgather = nullptr;
+nccl_errstr_fn g_nccl_errstr = nullptr;
+bool find_rccl()
+{
+    std::lock_guard<std::mutex> lock(g_rccl_mutex);
+    if (g_nccl_allgather) return true;
+    void *sym = dlsym(RTLD_DEFAULT, "ncclAllGather");
+    void *es = sym ? dlsym(RTLD_DEFAULT, "ncclGetErrorString") : nullptr;
+    if (!sym) {
+        const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+        void *h = nullptr;
+        for (const char *n : names)
+            if ((h = dlopen(n, RTLD_NOW | RTLD_NOLOAD))) break;   // a copy the process has loaded already
+        for (size_t i = 0; !h && i < sizeof names / sizeof *names; ++i) h = dlopen(names[i], RTLD_NOW | RTLD_LOCAL);
+        if (h) { sym = dlsym(h, "ncclAllGather"); es = dlsym(h, "ncclGetErrorString"); }
+    }
+    g_nccl_errstr = (nccl_errstr_fn)es;
+    g_nccl_allgather = (nccl_allgather_fn)sym;
+    return g_nccl_allgather != nullptr;
+}
+}  // namespace
+
+int mp_allgather_results(mp_ctx *ctx, void *nccl_comm, const void *send, void *recv, size_t bytes_per_rank)
+{
+    DeviceGuard guard_;
+    int rc = guard_.enter(ctx);
+    if (rc) return rc;
+    if (!nccl_comm || !send || !recv) return fail(ctx, MP_E_ARG, "mp_allgather_results: NULL argument");
+    if (bytes_per_rank == 0) return MP_OK;
+    if (!find_rccl()) return fail(ctx, MP_E_UNSUPPORTED, "mp_allgather_results: no RCCL in this process (ncclAllGather not found; %s)", dlerror());
+    const int r = g_nccl_allgather(send, recv, bytes_per_rank, 1 /* ncclUint8 */, nccl_comm, ctx->stream);
+    if (r != 0) return fail(ctx, MP_E_HIP, "ncclAllGather failed: %s", g_nccl_errstr ? g_nccl_errstr(r) : "unknown RCCL error");
     return MP_OK;
 }
 

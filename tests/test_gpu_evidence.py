@@ -421,3 +421,18 @@ def test_seed_grid_group_size_and_prefilter_change_no_result(native, oracle_lib,
             assert a.keys() == b.keys()
             for k in a:
                 np.testing.assert_array_equal(a[k], b[k], err_msg=f"setting {settings[si]}: {k}")
+
+
+def test_plain_c_job_gathers_over_rccl(tmp_path):
+    """tests/cabi/cabi_gather.c: a C caller with an RCCL communicator of its own shards a job by candidate index, evaluates its
+    shard with mp_eval(MP_MEM_DEVICE) and exchanges the results with mp_allgather_results (one ncclAllGather of raw bytes on
+    the context's stream); the gathered bytes equal a local evaluation of all candidates.  One rank here (RCCL wants one GPU
+    per rank, the box has one); the program takes rank / n_ranks arguments for a real node."""
+    exe = ROOT / "tests" / "cabi" / "cabi_gather"
+    assert exe.exists(), "run __graft_entry__.build() first"
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([str(exe), "0", "1", str(tmp_path / "nccl_id"), "0"], capture_output=True, text=True, timeout=150, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert lines[-2].startswith("rank 0 of 1: gathered == local (512 candidates"), lines
+    assert lines[-1] == "null_comm rc=-1"
