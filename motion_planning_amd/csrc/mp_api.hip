@@ -497,7 +497,9 @@ template <typename T> int upload_problem(mp_ctx *ctx, const mp_task *tasks)
                 // its exact value bounds the sample's clearance before the sweep starts.  Only a heuristic: results do not
                 // depend on what a cell holds.
                 int grid_id = -1;
-                if (ctx->grid_mode && c.model == MP_MODEL_BOX && cnt >= 4) {
+                // (batches of many small scenarios - 10,000 tasks of <= 13 boxes - skip it: their launches are CEM populations, which
+                // bring seeds of their own, so 10,000 grid builds would only add host time to mp_set_problem)
+                if (ctx->grid_mode && c.model == MP_MODEL_BOX && cnt >= 4 && (cnt >= 16 || ctx->n_tasks <= 64)) {
                     double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
                     for (int k : order) {
                         const double *r = &ctx->h_boxes[(size_t)(b0 + k) * 6];
