@@ -1468,6 +1468,13 @@ __global__ void __launch_bounds__(256) cem_update_kernel(long long n_inst, int p
     const int wib = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int wpb = (int)(blockDim.x >> 6);
     T *V = reinterpret_cast<T *>(smem_raw) + (size_t)wib * pop;   // this wave's copy of the population costs
+    // instances still running are counted per block and added to the device counter ONCE per block: one atomic per instance
+    // on that single address (128,000 of them at config 5) took 1.07 of the kernel's 1.08 ms - a device-scope atomic on one
+    // address completes every ~12 ns on this multi-XCD part
+    __shared__ int block_active;
+    if (threadIdx.x == 0) block_active = 0;
+    __syncthreads();
+    int wave_active = 0;
     for (long long inst = (long long)blockIdx.x * wpb + wib; inst < n_inst; inst += (long long)gridDim.x * wpb) {
         if (st.done[inst]) continue;
         const T *v = vals + inst * pop;
@@ -1506,25 +1513,50 @@ __global__ void __launch_bounds__(256) cem_update_kernel(long long n_inst, int p
             }
             if (rank < n_elite) elite_bits |= 1u << j;
         }
-        // refit per dimension: mean, then population std (np.std, ddof = 0)
+        // refit per dimension: mean, then population std (np.std, ddof = 0).  Eight dimensions at a time: their loads are
+        // issued together and their wave sums are independent (one dimension after the other, the kernel waited for sixteen
+        // load round trips and sixteen dependent reductions per instance); every sum adds in the same order
+        // as before (per lane over its members, then across the wave), so the bits are unchanged.
         T max_sigma = T(0);
-        for (int d = 0; d < D; ++d) {
-            T acc = T(0);
-            for (int p = lane, j = 0; p < pop; p += 64, ++j)
-                if (elite_bits & (1u << j)) acc += x[(long long)p * D + d];
-            const T mean = wave_sum(acc) / (T)n_elite;
-            T acc2 = T(0);
+        for (int d0 = 0; d0 < D; d0 += 8) {
+            const int nd = D - d0 < 8 ? D - d0 : 8;
+            T acc[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc[u] = T(0);
             for (int p = lane, j = 0; p < pop; p += 64, ++j)
                 if (elite_bits & (1u << j)) {
-                    const T e = x[(long long)p * D + d] - mean;
-                    acc2 += e * e;
+                    const T *row = x + (long long)p * D + d0;
+#pragma unroll
+                    for (int u = 0; u < 8; ++u)
+                        if (u < nd) acc[u] += row[u];
                 }
-            const T sd = mp_sqrt(wave_sum(acc2) / (T)n_elite) + min_sigma;
-            const T mu_new = alpha * st.mu[inst * D + d] + (T(1) - alpha) * mean;
-            T sg_new = alpha * st.sigma[inst * D + d] + (T(1) - alpha) * sd;
-            sg_new = sg_new > min_sigma ? sg_new : min_sigma;
-            max_sigma = sg_new > max_sigma ? sg_new : max_sigma;
-            if (lane == 0) { st.mu[inst * D + d] = mu_new; st.sigma[inst * D + d] = sg_new; }
+            T mean[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) mean[u] = u < nd ? wave_sum(acc[u]) / (T)n_elite : T(0);
+            T acc2[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc2[u] = T(0);
+            for (int p = lane, j = 0; p < pop; p += 64, ++j)
+                if (elite_bits & (1u << j)) {
+                    const T *row = x + (long long)p * D + d0;
+#pragma unroll
+                    for (int u = 0; u < 8; ++u)
+                        if (u < nd) {
+                            const T e = row[u] - mean[u];
+                            acc2[u] += e * e;
+                        }
+                }
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (u < nd) {
+                    const int d = d0 + u;
+                    const T sd = mp_sqrt(wave_sum(acc2[u]) / (T)n_elite) + min_sigma;
+                    const T mu_new = alpha * st.mu[inst * D + d] + (T(1) - alpha) * mean[u];
+                    T sg_new = alpha * st.sigma[inst * D + d] + (T(1) - alpha) * sd;
+                    sg_new = sg_new > min_sigma ? sg_new : min_sigma;
+                    max_sigma = sg_new > max_sigma ? sg_new : max_sigma;
+                    if (lane == 0) { st.mu[inst * D + d] = mu_new; st.sigma[inst * D + d] = sg_new; }
+                }
         }
         if (lane == 0) {
             const T prev = st.prev_best[inst];
@@ -1532,11 +1564,14 @@ __global__ void __launch_bounds__(256) cem_update_kernel(long long n_inst, int p
             const T diff = prev - best_val;
             const bool stop = ((diff < T(0) ? -diff : diff) < tol) && (max_sigma < T(0.03));
             if (stop) st.done[inst] = 1;
-            else atomicAdd(st.n_active, 1);
+            else wave_active += 1;
             st.prev_best[inst] = best_val;
         }
         wave_lds_sync();
     }
+    if (lane == 0 && wave_active) atomicAdd(&block_active, wave_active);
+    __syncthreads();
+    if (threadIdx.x == 0 && block_active) atomicAdd(st.n_active, block_active);
 }
 
 template <typename T>
