@@ -1421,7 +1421,10 @@ int mp_allgather_results(mp_ctx *ctx, void *nccl_comm, const void *send, void *r
     if (rc) return rc;
     if (!nccl_comm || !send || !recv) return fail(ctx, MP_E_ARG, "mp_allgather_results: NULL argument");
     if (bytes_per_rank == 0) return MP_OK;
-    if (!find_rccl()) return fail(ctx, MP_E_UNSUPPORTED, "mp_allgather_results: no RCCL in this process (ncclAllGather not found; %s)", dlerror());
+    if (!find_rccl()) {
+        const char *why = dlerror();
+        return fail(ctx, MP_E_UNSUPPORTED, "mp_allgather_results: no RCCL in this process (ncclAllGather not found; %s)", why ? why : "no loader message");
+    }
     const int r = g_nccl_allgather(send, recv, bytes_per_rank, 1 /* ncclUint8 */, nccl_comm, ctx->stream);
     if (r != 0) return fail(ctx, MP_E_HIP, "ncclAllGather failed: %s", g_nccl_errstr ? g_nccl_errstr(r) : "unknown RCCL error");
     return MP_OK;

@@ -436,3 +436,29 @@ def test_plain_c_job_gathers_over_rccl(tmp_path):
     lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
     assert lines[-2].startswith("rank 0 of 1: gathered == local (512 candidates"), lines
     assert lines[-1] == "null_comm rc=-1"
+
+
+def test_full_config2_sweep_on_the_gpu(tmp_path):
+    """BASELINE config 2 as the reference runs it (example/benchmark_planners.py:308-318): the four generated scenarios x
+    {Powell, CEM, CEM-POWELL} x 12 random-search trials, --seed 7 = 120 solves through the drop-in planner on the HIP evaluator
+    (tools/run_sweep.py as a child process).  Every solve succeeds, no benchmarked path penetrates by a centimetre, the result file has the
+    reference's layout, and the Powell leg's mean cost is the one the builder recorded (the sweep is seeded end to end)."""
+    out = tmp_path / "benchmark_results.json"
+    r = subprocess.run([sys.executable, str(ROOT / "tools" / "run_sweep.py"), "--output", str(out)], capture_output=True, text=True,
+                       timeout=160, cwd=str(ROOT))
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "120 solves in" in r.stdout
+    d = json.loads(out.read_text())
+    assert d["methods"] == ["Powell", "CEM", "CEM-POWELL"] and d["trials_per_method"] == 12 and d["seed"] == 7 and d["solves"] == 120
+    assert len(d["train_scenarios"]) == 3 and len(d["test_scenarios"]) == 4
+    for m in d["methods"]:
+        assert len(d["hyperopt"][m]["trials"]) == 12
+        agg = d["benchmark"][m]["aggregate"]
+        assert agg["success_rate"] == 1.0 and np.isfinite(agg["mean_score"])
+        assert len(d["benchmark"][m]["per_scenario"]) == 4
+        # the score adds a runtime term to the cost (benchmark_planners.py:112-117), so only the cost itself is box independent
+        assert agg["metrics"]["fun"]["mean"] <= agg["mean_score"] and agg["metrics"]["min_clearance"]["min"] > -0.01
+    # costs of the builder's run on the final library (gpurun_out/benchmark_results.json of profiles/r03_config2_sweep.log)
+    recorded = {"Powell": 4.65415916557865}
+    for m, v in recorded.items():
+        assert d["benchmark"][m]["aggregate"]["metrics"]["fun"]["mean"] == pytest.approx(v, rel=1e-6), m
