@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Exact pair evaluations per candidate for every case of bench.py's workload sweep (-DMP_STATS build of the library:
 `tools/build_variant.sh stats -DMP_STATS`, then `MP_HIP_LIB=ab/libmp_stats.so python tools/workload_stats.py`).
-Writes profiles/r02_workload_stats.json, which bench.py merges into extras.workload_sweep."""
+Writes profiles/r03_workload_stats.json, which bench.py merges into extras.workload_sweep."""
 import ctypes as C
 import json
 import sys
@@ -35,4 +35,4 @@ for name, prob, X in cases:
                  "colliding_fraction": float((res["flags"] & 1).mean()), "sample": n}
     print(name, out[name], flush=True)
     ctx.close()
-(ROOT / "profiles" / "r02_workload_stats.json").write_text(json.dumps(out, indent=1))
+(ROOT / "profiles" / "r03_workload_stats.json").write_text(json.dumps(out, indent=1))
